@@ -1,0 +1,175 @@
+/*
+ * vggp.h -- C-ABI of libvggp_hip.so: the MI355X (gfx950) engine for the
+ * Kronecker-structured collapsed-ELBO hot path of
+ * maxnorman569/Variational-Gridded-Gaussian-Processes.
+ *
+ * The reference has NO FFI / plugin boundary (it is plain Python classes on
+ * gpytorch); this boundary is defined by the build.  Each entry
+ * point cites the reference code it replaces (paths relative to the reference
+ * checkout).  Host code (Python/ctypes) owns every data
+ * buffer; pointers marked DEVICE are hipMalloc'ed (e.g. torch tensor.data_ptr()),
+ * contiguous float64.  The library owns only the opaque context (workspace arena,
+ * HIP-graph cache).  Every function returns 0 on success or a negative VGGP_E*
+ * code; the message is available from vggp_last_error() (thread-local).  Nothing
+ * throws across the boundary.  One context per (process, device); not re-entrant.
+ * All work is enqueued on the hipStream_t passed as `stream` (void*, 0 = default).
+ *
+ * Conventions
+ *   theta[5] = { ell_1, ell_2, s_1, s_2, sigma2 }  (constrained values:
+ *              lengthscales, outputscales, likelihood.noise -- a variance,
+ *              kronecker_structure.py:263)
+ *   Y        : observations on the local grid shard, [n2][n1] row-major,
+ *              Y[j][i] = y(x1[i], x2[j])  (x1 fastest: utils/datagenerators.py:70-72)
+ *   inducing index u = i1*m2 + i2 (kronecker_structure.py:805, :822)
+ *   multi-GPU: the grid is sharded along the slow storage axis (rows j of Y, i.e.
+ *              dimension 2); dimension 1 and all m-space algebra are replicated.
+ */
+#ifndef VGGP_H
+#define VGGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGGP_VERSION 100          /* 0.1.0 */
+
+/* error codes */
+#define VGGP_OK        0
+#define VGGP_EINVAL   -1          /* bad argument / shape                          */
+#define VGGP_ENOTPD   -2          /* a factor is not PD after the jitter schedule  */
+#define VGGP_EHIP     -3          /* HIP runtime error                             */
+#define VGGP_ENOMEM   -4
+#define VGGP_ESTATE   -5          /* call order (e.g. finish before partials)      */
+#define VGGP_ENOCONV  -6          /* Jacobi eigensolver hit its sweep limit        */
+
+/* kernel family of one dimension (gpytorch MaternKernel(nu) / the build's RBF) */
+#define VGGP_KIND_MATERN12 0
+#define VGGP_KIND_MATERN32 1
+#define VGGP_KIND_MATERN52 2
+#define VGGP_KIND_RBF      3
+
+/* inducing-feature basis of one dimension */
+#define VGGP_BASIS_POINTS 0       /* pairwise k(z, x): Matern12SVGP, kronecker_structure.py:306-338 */
+#define VGGP_BASIS_B0     1       /* B0-spline cell integrals (Matern-1/2 only):
+                                     kronecker_structure.py:702-790 == gridded_kronecker_structure.py:1286-1374 */
+#define VGGP_BASIS_ONE    2       /* trivial factor K=[1], A=1: turns the engine into the 1-D model,
+                                     univariate_structure.py:234-263, :693-717 */
+
+typedef struct vggp_ctx vggp_ctx;
+
+/* Problem description (host struct; the small coordinate arrays are HOST pointers and
+ * are copied into the context by vggp_plan). */
+typedef struct vggp_desc {
+    int32_t kind1, basis1;        /* dimension 1 (x1, fast axis of Y)                 */
+    int32_t kind2, basis2;        /* dimension 2 (x2, slow axis of Y; sharded axis)   */
+    int64_t n1, n2;               /* LOCAL grid: Y is [n2][n1]                        */
+    int64_t m1, m2;               /* inducing features per dimension                  */
+    int64_t n_total;              /* number of observations over ALL ranks (N)        */
+    const double* x1;             /* HOST [n1]  unique coordinates along dim 1        */
+    const double* x2;             /* HOST [n2]  local coordinates along dim 2         */
+    const double* grid1;          /* HOST: mesh [m1+1] (B0) or inducing coords [m1]   */
+    const double* grid2;          /* HOST: mesh [m2+1] (B0) or inducing coords [m2]   */
+    int32_t warm_start;           /* 1: reuse the previous step's eigenvectors        */
+    int32_t reserved;
+} vggp_desc;
+
+/* per-step diagnostics (host struct filled by vggp_elbo_finish / vggp_elbo_step) */
+typedef struct vggp_info {
+    double jitter1, jitter2;      /* jitter actually added to the unit-scale factors  */
+    int32_t sweeps1, sweeps2;     /* Jacobi sweeps used                               */
+    int32_t rounds1, rounds2;     /* Jacobi rotation rounds applied                   */
+    int32_t status;               /* 0 or a VGGP_E* code detected on the device       */
+    int32_t reserved;
+} vggp_info;
+
+int         vggp_version(void);
+const char* vggp_last_error(void);
+
+/* lifecycle ---------------------------------------------------------------- */
+int vggp_create(vggp_ctx** out, int device);
+int vggp_destroy(vggp_ctx* ctx);
+/* (Re)plan the context for a problem: allocates the workspace arena (no allocation
+ * happens per step afterwards) and uploads coordinates / meshes.
+ * Replaces: KroneckerStructure.__init__ + Matern12GriddedGP.__init__ bookkeeping
+ * (kronecker_structure.py:19-32, gridded_kronecker_structure.py:1259-1284). */
+int vggp_plan(vggp_ctx* ctx, const vggp_desc* desc);
+/* Number of doubles in the all-reduce payload {G2,H2,C,C1,C2} of the planned problem. */
+int64_t vggp_payload_len(const vggp_ctx* ctx);
+int64_t vggp_workspace_bytes(const vggp_ctx* ctx);
+
+/* the hot path ------------------------------------------------------------- */
+/* One ELBO step = value + gradient w.r.t. theta.  Replaces KroneckerStructure._elbo
+ * (kronecker_structure.py:249-278) AND the autograd backward of the notebook loop
+ * (5_gridded_kronecker_structure_models.ipynb cell 26).
+ *   Y        DEVICE [n2][n1]
+ *   yy_total sum of y^2 over ALL ranks (constant of the data; vggp_sumsq helps)
+ *   elbo_out, grad_out[5]  HOST outputs (the only host sync of the step)
+ * Single-rank convenience = vggp_elbo_partials + vggp_elbo_finish. */
+int vggp_elbo_step(vggp_ctx* ctx, const double* Y, double yy_total, const double theta[5],
+                   double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
+
+/* Multi-GPU split: partials fills `payload` (DEVICE, vggp_payload_len doubles) with this
+ * rank's contribution; the caller sums it over ranks with ONE all-reduce (RCCL via
+ * torch.distributed) and passes the reduced buffer to finish. */
+int vggp_elbo_partials(vggp_ctx* ctx, const double* Y, const double theta[5],
+                       double* payload, void* stream);
+int vggp_elbo_finish(vggp_ctx* ctx, const double* payload, double yy_total, const double theta[5],
+                     double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
+
+/* q(v) of the last finished step: mean and diagonal of the covariance, both DEVICE
+ * [m1][m2] (flat index u = i1*m2+i2).  Replaces Matern12GriddedGP.q_v
+ * (gridded_kronecker_structure.py:1409-1433 == kronecker_structure.py:825-849). */
+int vggp_qv(vggp_ctx* ctx, double* mean, double* var, void* stream);
+/* Dense M x M covariance Kuu Sigma^{-1} Kuu of q(v) (DEVICE, M = m1*m2; small M only). */
+int vggp_qv_cov(vggp_ctx* ctx, double* cov, void* stream);
+
+/* Point-wise posterior at ns scattered test points (xs1[p], xs2[p]) (DEVICE inputs):
+ * mean[ns], var[ns] (DEVICE).  Replaces KroneckerStructure.posterior mean and the
+ * diagonal of its covariance (kronecker_structure.py:199-230). */
+int vggp_posterior(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t ns,
+                   double* mean, double* var, void* stream);
+
+/* building blocks (exported for tests, benchmarks and re-use) ---------------- */
+/* Unit-outputscale factor build for one dimension: A0[m][n], dA0/d ell [m][n],
+ * K0[m][m], dK0/d ell [m][m] (any output pointer may be NULL).  x DEVICE [n];
+ * grid DEVICE ([m+1] mesh for B0, [m] coords for POINTS).
+ * Replaces _Kuu_along_dim/_Kuf_along_dim (kronecker_structure.py:702-790) and the
+ * pairwise kernel_d(Z), kernel(Z, x) evaluations (:318-319, :336-337). */
+int vggp_factor_build(vggp_ctx* ctx, int kind, int basis, const double* x, int64_t n,
+                      const double* grid, int64_t m, double ell,
+                      double* A0, double* dA0, double* K0, double* dK0, void* stream);
+
+/* Cholesky K + jitter*I = L L^T with the psd_safe_cholesky jitter schedule (0, 1e-8,
+ * 1e-7, 1e-6) and the explicit inverse of L.  K, L, Linv DEVICE [m][m] row-major.
+ * Replaces the Cholesky hidden inside lazify(Kuu).inv_matmul (kronecker_structure.py:269).
+ * jitter_out HOST (may be NULL). */
+int vggp_cholesky_inverse(vggp_ctx* ctx, const double* K, int64_t m, double* L, double* Linv,
+                          double* jitter_out, void* stream);
+
+/* Symmetric eigendecomposition G = Q diag(lam) Q^T by parallel cyclic Jacobi.
+ * G DEVICE [m][m]; lam DEVICE [m]; Qt DEVICE [m][m] with ROW j = eigenvector j. */
+int vggp_eigh(vggp_ctx* ctx, const double* G, int64_t m, double* lam, double* Qt,
+              int32_t* sweeps_out, void* stream);
+
+/* Strided fp64 MFMA GEMM  C[M][N] = op(A) op(B)  with element (i,k) of op(A) at
+ * A[i*sa_m + k*sa_k] and (k,j) of op(B) at B[k*sb_k + j*sb_n]; C row-major, ld = ldc. */
+int vggp_gemm(vggp_ctx* ctx, const double* A, int64_t sa_m, int64_t sa_k,
+              const double* B, int64_t sb_k, int64_t sb_n,
+              double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* Kronecker solve  X = K1^{-1} Y K2^{-T}  from Cholesky factors, applied as
+ * L^{-T}(L^{-1} .) on each side without materialising K1 (x) K2 (BASELINE metric ii).
+ * L1inv [n1][n1], L2inv [n2][n2] (from vggp_cholesky_inverse), Y, X DEVICE [n1][n2].
+ * Replaces Kuu.inv_matmul(.) with Kuu = torch.kron(Kuu_1, Kuu_2) (kronecker_structure.py:269, :805). */
+int vggp_kron_solve(vggp_ctx* ctx, const double* L1inv, int64_t n1, const double* L2inv, int64_t n2,
+                    const double* Y, double* X, void* stream);
+
+/* sum of squares of a DEVICE array (for yy_total); result to HOST. */
+int vggp_sumsq(vggp_ctx* ctx, const double* y, int64_t n, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGGP_H */

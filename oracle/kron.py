@@ -1,0 +1,307 @@
+"""Structured (Kronecker) CPU twin of the HIP engine (TEST INFRASTRUCTURE / cpu_baseline "port").
+
+Computes the SAME numbers as oracle/dense.py -- the collapsed ELBO of
+kronecker_structure.py:249-278, q(v) of :825-849 and the posterior of :199-230 --
+from the per-dimension factors only, never forming anything of size N x N or
+M x N.  numpy float64 + LAPACK (scipy); the hyper-parameter
+gradient is analytic (no autograd).  The HIP engine implements exactly this
+algorithm; this file is its readable specification and the timed CPU baseline.
+
+Layout: observations Y[j, i] = y(x1[i], x2[j]) stored [n2, n1] row-major (x1
+fastest: src/utils/datagenerators.py:70-72).  Inducing index u = i1*m2 + i2
+(kronecker_structure.py:805, :822).  theta = [ell1, ell2, s1, s2, sigma2].
+
+Jitter policy: K_d = s_d * (kappa_d + eps_d I) with eps_d the first of
+(0, 1e-8, 1e-7, 1e-6) for which the Cholesky of the unit-outputscale factor
+succeeds (so K_d scales exactly with s_d; eps_d = 0 for the reference's
+Matern-1/2 models).  oracle/dense.py applies the same policy.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.linalg as sla
+
+JITTERS = (0.0, 1e-8, 1e-7, 1e-6)
+NOISE_LOWER = 1e-4
+SQ3, SQ5 = math.sqrt(3.0), math.sqrt(5.0)
+
+
+# ----------------------------------------------------------------------------
+# factor builders: value and d/d ell (unit outputscale; callers multiply by s)
+# ----------------------------------------------------------------------------
+def kappa_and_dell(kind: str, dist: np.ndarray, ell: float):
+    r = dist / ell
+    if kind == "matern12":
+        e = np.exp(-r)
+        return e, e * r / ell
+    if kind == "matern32":
+        a = SQ3 * r
+        e = np.exp(-a)
+        return (1 + a) * e, a * a * e / ell
+    if kind == "matern52":
+        a = SQ5 * r
+        e = np.exp(-a)
+        return (1 + a + a * a / 3) * e, (a * a / 3) * (1 + a) * e / ell
+    if kind == "rbf":
+        e = np.exp(-0.5 * r * r)
+        return e, e * r * r / ell
+    raise ValueError(kind)
+
+
+def points_factor(kind, z, x, ell):
+    """A0[k,p] = kappa(|z_k - x_p|/ell), dA0/dell  (kronecker_structure.py:318-319, :336-337)."""
+    return kappa_and_dell(kind, np.abs(z[:, None] - x[None, :]), ell)
+
+
+def b0_K(m: int, delta: float, ell: float):
+    """Unit-outputscale Kuu_d and d/dell (kronecker_structure.py:723-739), stable form:
+    r_k = exp(-k t) * 4 sinh^2(t/2), r_0 = 2 (expm1(-t) + t), t = delta/ell."""
+    t = delta / ell
+    k = np.arange(m, dtype=np.float64)
+    r = np.exp(-k * t) * (4.0 * math.sinh(0.5 * t) ** 2)
+    r[0] = 2.0 * (math.expm1(-t) + t)
+    # dr_k/dell = (delta/ell^2) [(k-1)e^{-(k-1)t} + (k+1)e^{-(k+1)t} - 2k e^{-kt}]
+    #           = (t/ell) e^{-kt} [k*4sinh^2(t/2) - 2 sinh(t)]
+    dr = (t / ell) * np.exp(-k * t) * (k * 4.0 * math.sinh(0.5 * t) ** 2 - 2.0 * math.sinh(t))
+    dr[0] = (2.0 * t / ell) * math.expm1(-t)
+    idx = np.abs(np.arange(m)[:, None] - np.arange(m)[None, :])
+    T, dT = r[idx], dr[idx]
+    return ell * ell * T, 2.0 * ell * T + ell * ell * dT
+
+
+def b0_A(mesh: np.ndarray, x: np.ndarray, ell: float):
+    """Unit-outputscale Kuf_d and d/dell (kronecker_structure.py:768-790).  Cell k is
+    (mesh[k], mesh[k+1]] (searchsorted right=False), x <= mesh[0] counts as below."""
+    a, b = mesh[:-1, None], mesh[1:, None]
+    xx = x[None, :]
+    ua, ub = np.abs(xx - a), np.abs(xx - b)
+    ea, eb = np.exp(-ua / ell), np.exp(-ub / ell)
+    E1, E2 = ell * ea, ell * eb
+    dE1, dE2 = ea * (1 + ua / ell), eb * (1 + ub / ell)
+    inside = (xx > a) & (xx <= b)
+    sign = np.where(xx <= a, 1.0, -1.0)
+    A = np.where(inside, 2 * ell - (E1 + E2), sign * (E1 - E2))
+    dA = np.where(inside, 2 - (dE1 + dE2), sign * (dE1 - dE2))
+    return A, dA
+
+
+@dataclass
+class Factor:
+    """One dimension's inducing-feature description."""
+    basis: str                  # "b0" | "points" | "one" (trivial factor for 1-D models)
+    kind: str                   # matern12 | matern32 | matern52 | rbf
+    grid: np.ndarray            # mesh (m+1 knots) for b0, inducing coords (m) for points
+    x: np.ndarray               # the n_d unique observation coordinates along this dim
+
+    @property
+    def m(self) -> int:
+        if self.basis == "one":
+            return 1
+        return len(self.grid) - 1 if self.basis == "b0" else len(self.grid)
+
+    def build(self, ell: float, x: Optional[np.ndarray] = None):
+        """-> (K0, dK0, A0, dA0) at unit outputscale."""
+        x = self.x if x is None else x
+        if self.basis == "one":
+            o = np.ones((1, len(x)))
+            return np.ones((1, 1)), np.zeros((1, 1)), o, np.zeros_like(o)
+        g = np.asarray(self.grid, dtype=np.float64)
+        if self.basis == "b0":
+            K, dK = b0_K(len(g) - 1, float(g[1] - g[0]), ell)
+            A, dA = b0_A(g, x, ell)
+        else:
+            K, dK = points_factor(self.kind, g, g, ell)
+            A, dA = points_factor(self.kind, g, x, ell)
+        return K, dK, A, dA
+
+
+def chol_jitter(K0: np.ndarray) -> Tuple[np.ndarray, float]:
+    for jit in JITTERS:
+        try:
+            L = np.linalg.cholesky(K0 + jit * np.eye(K0.shape[0]))
+            if np.isfinite(L).all():
+                return L, jit
+        except np.linalg.LinAlgError:
+            pass
+    raise np.linalg.LinAlgError("factor not positive definite after jitter 1e-6")
+
+
+# ----------------------------------------------------------------------------
+# per-dimension "B-basis" quantities (everything that touches n_d-sized data)
+# ----------------------------------------------------------------------------
+@dataclass
+class DimState:
+    L: np.ndarray       # chol(s*(K0+eps I))
+    jit: float
+    B: np.ndarray       # L^{-1} A            (m x n)
+    V: np.ndarray       # L^{-1} dA/dell      (m x n)
+    Mk: np.ndarray      # L^{-1} dK/dell L^{-T}  (m x m)
+    G: Optional[np.ndarray] = None    # B B^T   (summed over ranks)
+    H: Optional[np.ndarray] = None    # V B^T
+    lam: Optional[np.ndarray] = None
+    Q: Optional[np.ndarray] = None
+
+
+def dim_prepare(f: Factor, ell: float, s: float, cols: Optional[slice] = None) -> DimState:
+    K0, dK0, A0, dA0 = f.build(ell)
+    L0, jit = chol_jitter(K0)
+    L = math.sqrt(s) * L0
+    A, dA = s * A0, s * dA0
+    if cols is not None:
+        A, dA = A[:, cols], dA[:, cols]
+    B = sla.solve_triangular(L, A, lower=True)
+    V = sla.solve_triangular(L, dA, lower=True)
+    X = sla.solve_triangular(L, s * dK0, lower=True)
+    Mk = sla.solve_triangular(L, X.T, lower=True).T
+    return DimState(L=L, jit=jit, B=B, V=V, Mk=Mk)
+
+
+@dataclass
+class StepState:
+    theta: np.ndarray
+    d1: DimState
+    d2: DimState
+    P: np.ndarray
+    D: np.ndarray
+    beta: np.ndarray
+    N: int
+    yy: float
+    elbo: float = 0.0
+    grad: np.ndarray = field(default_factory=lambda: np.zeros(5))
+
+
+def local_partials(Y: np.ndarray, d1: DimState, d2: DimState):
+    """What one rank contributes before the single all-reduce: the packed payload
+    {G2, H2, C, C1, C2, yy} for the rows of Y it owns (dim-2 shard), plus the
+    replicated dim-1 Gram pair.  Y: [n2_local, n1]."""
+    S = Y.T @ np.vstack([d2.B, d2.V]).T          # (n1, 2 m2) -- the only pass over Y
+    m2 = d2.B.shape[0]
+    C = d1.B @ S[:, :m2]
+    C1 = d1.V @ S[:, :m2]
+    C2 = d1.B @ S[:, m2:]
+    G2 = d2.B @ d2.B.T
+    H2 = d2.V @ d2.B.T
+    yy = float((Y * Y).sum())
+    return dict(G2=G2, H2=H2, C=C, C1=C1, C2=C2, yy=yy)
+
+
+def finish(theta, d1: DimState, d2: DimState, pay: dict, N: int) -> StepState:
+    """m-space part: eig, rotations, ELBO and its analytic gradient (replicated on every rank)."""
+    ell1, ell2, s1, s2, v = [float(t) for t in theta]
+    d1.G, d1.H = d1.B @ d1.B.T, d1.V @ d1.B.T
+    d2.G, d2.H = pay["G2"], pay["H2"]
+    for d in (d1, d2):
+        d.lam, d.Q = np.linalg.eigh(d.G)
+    Q1, Q2, l1, l2 = d1.Q, d2.Q, d1.lam, d2.lam
+    m1, m2 = len(l1), len(l2)
+    P = Q1.T @ pay["C"] @ Q2
+    P1 = Q1.T @ pay["C1"] @ Q2
+    P2 = Q1.T @ pay["C2"] @ Q2
+    a = np.outer(l1, l2) / v
+    D = 1.0 + a
+    beta = P / D
+    yy = pay["yy"]
+    sl1, sl2 = l1.sum(), l2.sum()
+    elbo = (-0.5 * (N * math.log(2 * math.pi) + N * math.log(v) + np.log(D).sum()
+                    + yy / v - (P * beta).sum() / v ** 2)
+            - (N * s1 * s2 - sl1 * sl2) / (2 * v))
+
+    def ell_grad(dd: DimState, Pd, lam_other_sum, m_other, r, rlam, X, Xlam, lam_self):
+        E = dd.Q.T @ dd.Mk @ dd.Q
+        F = dd.Q.T @ (dd.H + dd.H.T) @ dd.Q
+        e, f = np.diag(E), np.diag(F)
+        quad = 2 * (beta * Pd).sum() - (E * X).sum() - (F * Xlam).sum() / v
+        return (-0.5 * ((e * r).sum() + (f * rlam).sum() / v - m_other * e.sum() - quad / v ** 2)
+                + lam_other_sum / (2 * v) * (f.sum() - (e * lam_self).sum()))
+
+    invD = 1.0 / D
+    g_ell1 = ell_grad(d1, P1, sl2, m2, invD.sum(1), (invD * l2[None, :]).sum(1),
+                      beta @ beta.T, (beta * l2[None, :]) @ beta.T, l1)
+    g_ell2 = ell_grad(d2, P2, sl1, m1, invD.sum(0), (invD * l1[:, None]).sum(0),
+                      beta.T @ beta, (beta * l1[:, None]).T @ beta, l2)
+    saD = (a * invD).sum()
+    sb2 = (beta * beta).sum()
+    g_s1 = -0.5 * (saD - sb2 / v ** 2) / s1 + sl1 * sl2 / (2 * v * s1) - N * s2 / (2 * v)
+    g_s2 = -0.5 * (saD - sb2 / v ** 2) / s2 + sl1 * sl2 / (2 * v * s2) - N * s1 / (2 * v)
+    g_v = (-0.5 * (N / v - saD / v - yy / v ** 2 + (beta * beta * (2 + a)).sum() / v ** 3)
+           + (N * s1 * s2 - sl1 * sl2) / (2 * v ** 2))
+    st = StepState(theta=np.asarray(theta, float), d1=d1, d2=d2, P=P, D=D, beta=beta, N=N, yy=yy)
+    st.elbo = float(elbo)
+    st.grad = np.array([g_ell1, g_ell2, g_s1, g_s2, g_v])
+    return st
+
+
+def elbo_step(Y: np.ndarray, f1: Factor, f2: Factor, theta, n_ranks: int = 1) -> StepState:
+    """Full-grid ELBO + d/dtheta.  n_ranks>1 emulates the dim-2 (row) shard + one all-reduce."""
+    ell1, ell2, s1, s2, v = [float(t) for t in theta]
+    n2, n1 = Y.shape
+    d1 = dim_prepare(f1, ell1, s1)
+    pays = []
+    bounds = np.linspace(0, n2, n_ranks + 1).astype(int)
+    d2_full = None
+    for r in range(n_ranks):
+        sl = slice(bounds[r], bounds[r + 1])
+        d2 = dim_prepare(f2, ell2, s2, cols=sl)
+        pays.append(local_partials(Y[sl], d1, d2))
+        d2_full = d2
+    pay = {k: sum(p[k] for p in pays) for k in pays[0]}      # the all-reduce
+    if n_ranks > 1:
+        d2_full = dim_prepare(f2, ell2, s2)
+    return finish(theta, d1, d2_full, pay, N=n1 * n2)
+
+
+def grad_raw(grad_theta: np.ndarray, raw: np.ndarray) -> np.ndarray:
+    """Chain rule through softplus (gpytorch Positive / GreaterThan(1e-4))."""
+    return grad_theta / (1.0 + np.exp(-np.asarray(raw, float)))
+
+
+def theta_from_raw(raw) -> np.ndarray:
+    raw = np.asarray(raw, float)
+    th = np.logaddexp(0.0, raw)
+    th[-1] += NOISE_LOWER
+    return th
+
+
+# ----------------------------------------------------------------------------
+# q(v) and posterior from a finished step
+# ----------------------------------------------------------------------------
+def q_v(st: StepState):
+    """mean (m1, m2) [flat index u = i1*m2+i2] and diag of the covariance (m1, m2);
+    kronecker_structure.py:846, :848."""
+    v = st.theta[4]
+    R1, R2 = st.d1.L @ st.d1.Q, st.d2.L @ st.d2.Q
+    mean = R1 @ (st.beta / v) @ R2.T
+    var = (R1 * R1) @ (1.0 / st.D) @ (R2 * R2).T
+    return mean, var
+
+
+def q_v_cov(st: StepState) -> np.ndarray:
+    """Dense M x M covariance Kuu Sigma^{-1} Kuu (small M only)."""
+    R = np.kron(st.d1.L @ st.d1.Q, st.d2.L @ st.d2.Q)
+    return (R / st.D.reshape(-1)[None, :]) @ R.T
+
+
+def posterior(st: StepState, f1: Factor, f2: Factor, x_star: np.ndarray):
+    """Point-wise posterior mean and variance at x_star (N*, 2); kronecker_structure.py:222-227."""
+    ell1, ell2, s1, s2, v = st.theta
+    Ts = []
+    for f, d, ell, s, col in ((f1, st.d1, ell1, s1, 0), (f2, st.d2, ell2, s2, 1)):
+        _, _, A0, _ = f.build(ell, x=np.asarray(x_star[:, col], float))
+        Ts.append(d.Q.T @ sla.solve_triangular(d.L, s * A0, lower=True))
+    T1, T2 = Ts
+    mean = np.einsum("ip,ij,jp->p", T1, st.beta / v, T2)
+    var = s1 * s2 + np.einsum("ip,ij,jp->p", T1 * T1, 1.0 / st.D - 1.0, T2 * T2)
+    return mean, var
+
+
+# ----------------------------------------------------------------------------
+# Kron solve  X = K1^{-1} Y K2^{-T}  from Cholesky factors (BASELINE metric ii)
+# ----------------------------------------------------------------------------
+def kron_solve(L1: np.ndarray, L2: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    """(K1 (x) K2)^{-1} vec(Y) matricised: Y is (n1, n2), K_d = L_d L_d^T."""
+    T = sla.cho_solve((L1, True), Y)
+    return sla.cho_solve((L2, True), T.T).T

@@ -1,0 +1,110 @@
+"""GPU unit tests of the exported building blocks (C-ABI) against float64 torch/numpy references."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kron as Kr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 1024, 128), (50, 37, 29), (256, 100, 1000), (1, 5, 3)])
+def test_gemm_layouts(engine, shape):
+    """All four operand orientations; asymmetric data so a transposed fragment map cannot hide."""
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(1)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64).to(DEV)
+    B = torch.randn(K, N, generator=g, dtype=torch.float64).to(DEV)
+    At = A.t().contiguous().t()      # M-contiguous view of the same values
+    Bt = B.t().contiguous().t()      # K-contiguous view
+    ref = (A.cpu() @ B.cpu()).numpy()
+    for a in (A, At):
+        for b in (B, Bt):
+            out = engine.gemm(a, b).cpu().numpy()
+            assert rel(out, ref) < 1e-13, (a.stride(), b.stride())
+
+
+def test_gemm_identity_asymmetric(engine):
+    A = torch.eye(64, dtype=torch.float64, device=DEV)
+    B = (torch.arange(64 * 64, dtype=torch.float64, device=DEV).reshape(64, 64) * 1.0)
+    assert torch.equal(engine.gemm(A, B), B)
+    assert torch.equal(engine.gemm(B, A), B)
+
+
+@pytest.mark.parametrize("kind", ["matern12", "matern32", "matern52", "rbf"])
+def test_factor_build_points(engine, kind):
+    x = np.linspace(0, 1, 301)
+    z = np.linspace(0, 1, 40)
+    ell = 0.23
+    A, dA, K, dK = engine.factor_build(kind, "points", torch.tensor(x, device=DEV), torch.tensor(z, device=DEV), ell)
+    rA, rdA = Kr.points_factor(kind, z, x, ell)
+    rK, rdK = Kr.points_factor(kind, z, z, ell)
+    for got, ref in ((A, rA), (dA, rdA), (K, rK), (dK, rdK)):
+        assert rel(got.cpu().numpy(), ref) < 1e-13
+
+
+def test_factor_build_b0(engine):
+    x = np.concatenate([np.linspace(0, 1, 257), [0.0, 1.0, 0.25, 0.5]])   # includes knots and both ends
+    mesh = np.linspace(0, 1, 33)
+    ell = 0.31
+    A, dA, K, dK = engine.factor_build("matern12", "b0", torch.tensor(x, device=DEV), torch.tensor(mesh, device=DEV), ell)
+    rA, rdA = Kr.b0_A(mesh, x, ell)
+    rK, rdK = Kr.b0_K(32, mesh[1] - mesh[0], ell)
+    for got, ref in ((A, rA), (dA, rdA), (K, rK), (dK, rdK)):
+        assert rel(got.cpu().numpy(), ref) < 1e-12
+
+
+@pytest.mark.parametrize("m,kind,ell", [(7, "matern12", 0.3), (64, "matern32", 0.2), (128, "matern52", 0.2),
+                                        (128, "rbf", 0.2), (150, "matern32", 0.1)])
+def test_cholesky_inverse(engine, m, kind, ell):
+    z = np.linspace(0, 1, m)
+    K, _ = Kr.points_factor(kind, z, z, ell)
+    L, Li, jit = engine.cholesky_inverse(torch.tensor(K, device=DEV))
+    Lr, jr = Kr.chol_jitter(K)
+    assert jit == jr
+    L, Li = L.cpu().numpy(), Li.cpu().numpy()
+    Kj = K + jit * np.eye(m)
+    assert rel(L @ L.T, Kj) < 1e-13
+    assert np.abs(np.triu(L, 1)).max() == 0 and np.abs(np.triu(Li, 1)).max() == 0
+    # L Li = I to conditioning
+    assert np.abs(L @ Li - np.eye(m)).max() < 1e-9 * max(1.0, np.linalg.cond(Lr) * 1e-4)
+
+
+@pytest.mark.parametrize("m,kind", [(1, "matern12"), (9, "matern12"), (64, "rbf"), (128, "matern32"), (150, "matern12")])
+def test_eigh(engine, m, kind):
+    xx = np.linspace(0, 1, 4 * m + 3)
+    f = Kr.Factor("points", kind, np.linspace(0, 1, m), xx)
+    d = Kr.dim_prepare(f, 0.2, 1.0)
+    G = d.B @ d.B.T
+    lam, Qt, sweeps = engine.eigh(torch.tensor(G, device=DEV))
+    lam, Qt = lam.cpu().numpy(), Qt.cpu().numpy()
+    w = np.linalg.eigvalsh(G)
+    assert np.abs(np.sort(lam) - w).max() < 1e-12 * w.max()
+    assert np.abs(Qt @ Qt.T - np.eye(m)).max() < 1e-11
+    assert np.linalg.norm(Qt @ G @ Qt.T - np.diag(lam)) < 1e-11 * np.linalg.norm(G)
+    assert 1 <= sweeps < 60
+
+
+def test_kron_solve(engine):
+    n1, n2 = 96, 130
+    K1, _ = Kr.points_factor("matern32", np.linspace(0, 1, n1), np.linspace(0, 1, n1), 0.1)
+    K2, _ = Kr.points_factor("matern12", np.linspace(0, 1, n2), np.linspace(0, 1, n2), 0.3)
+    Y = np.random.default_rng(0).standard_normal((n1, n2))
+    _, L1i, _ = engine.cholesky_inverse(torch.tensor(K1, device=DEV))
+    _, L2i, _ = engine.cholesky_inverse(torch.tensor(K2, device=DEV))
+    X = engine.kron_solve(L1i, L2i, torch.tensor(Y, device=DEV)).cpu().numpy()
+    ref = Kr.kron_solve(np.linalg.cholesky(K1), np.linalg.cholesky(K2), Y)
+    assert rel(X, ref) < 1e-9
+    # size-independent property: K1 X K2^T == Y
+    assert rel(K1 @ X @ K2.T, Y) < 1e-9
+
+
+def test_sumsq(engine):
+    y = torch.randn(100003, dtype=torch.float64, device=DEV)
+    assert abs(engine.sumsq(y) - float((y * y).sum())) < 1e-9 * float((y * y).sum())

@@ -1,0 +1,94 @@
+"""GPU parity of the ELBO step / q(v) / posterior against the CPU oracle (rtol 1e-5 is the
+north-star tolerance; float64 agreement is far tighter and asserted at 1e-7 here)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense as D
+from oracle import kron as Kr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+RTOL = 1e-7
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def run_case(engine, n1, n2, basis, kind, g1, g2, theta, warm=False):
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    f1 = Kr.Factor(basis, kind, np.asarray(g1, float), x1)
+    f2 = Kr.Factor(basis, kind, np.asarray(g2, float), x2)
+    st = Kr.elbo_step(y.reshape(n2, n1), f1, f2, theta)
+    engine.plan(kind, basis, g1, x1, kind, basis, g2, x2, warm_start=warm)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    yy = engine.sumsq(Y)
+    elbo, grad, info = engine.elbo_step(Y, yy, theta)
+    return st, elbo, grad, info, (f1, f2)
+
+
+CASES = [
+    (24, 20, "b0", "matern12", np.linspace(0, 1, 8), np.linspace(0, 1, 10), [0.2, 0.3, 1.0, 0.8, 0.01]),
+    (16, 12, "points", "matern12", np.linspace(0, 1, 9), np.linspace(0, 1, 7), [0.2, 0.3, 1.0, 0.8, 0.01]),
+    (32, 32, "points", "matern32", np.linspace(0, 1, 24), np.linspace(0, 1, 24), [0.2, 0.2, 1.0, 1.0, 0.0025]),
+    (40, 33, "points", "matern52", np.linspace(0, 1, 17), np.linspace(0, 1, 12), [0.25, 0.2, 1.3, 0.7, 0.01]),
+    (64, 64, "points", "rbf", np.linspace(0, 1, 32), np.linspace(0, 1, 32), [0.2, 0.2, 1.0, 1.0, 0.0025]),
+    (256, 256, "points", "rbf", np.linspace(0, 1, 64), np.linspace(0, 1, 64), [0.2, 0.2, 1.0, 1.0, 0.0025]),
+    (200, 300, "b0", "matern12", np.linspace(0, 1, 33), np.linspace(0, 1, 21), [0.6931, 0.6931, 0.6931, 0.6931, 0.6932]),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[2]}-{c[3]}-{c[0]}x{c[1]}")
+def test_elbo_step_vs_oracle(engine, case):
+    st, elbo, grad, info, fs = run_case(engine, *case)
+    assert info["status"] == 0
+    assert info["jitter"] == (st.d1.jit, st.d2.jit)
+    assert abs(elbo - st.elbo) <= RTOL * abs(st.elbo)
+    assert rel(grad, st.grad) < RTOL
+    mean, var = engine.qv()
+    rm, rv = Kr.q_v(st)
+    assert rel(mean.cpu().numpy(), rm) < RTOL
+    assert rel(var.cpu().numpy(), rv) < RTOL
+    xs = np.random.default_rng(5).uniform(0, 1, (1000, 2))
+    pm, pv = engine.posterior(torch.tensor(xs, device=DEV))
+    om, ov = Kr.posterior(st, fs[0], fs[1], xs)
+    assert rel(pm.cpu().numpy(), om) < RTOL
+    assert rel(pv.cpu().numpy(), ov) < 1e-6
+
+
+def test_qv_cov_small(engine):
+    st, *_ = run_case(engine, 24, 20, "b0", "matern12", np.linspace(0, 1, 8), np.linspace(0, 1, 10),
+                      [0.2, 0.3, 1.0, 0.8, 0.01])
+    cov = engine.qv_cov().cpu().numpy()
+    assert rel(cov, Kr.q_v_cov(st)) < RTOL
+
+
+def test_warm_start_tracks_cold(engine):
+    """A short hyper-parameter trajectory with warm-started eigensolves equals cold solves."""
+    n, m = 128, 32
+    X, y, x1, x2 = D.gen_grid(n, n)
+    g = np.linspace(0, 1, m)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    engine.plan("matern32", "points", g, x1, "matern32", "points", g, x2, warm_start=True)
+    yy = engine.sumsq(Y)
+    theta = np.array([0.2, 0.25, 1.0, 0.9, 0.01])
+    f1, f2 = Kr.Factor("points", "matern32", g, x1), Kr.Factor("points", "matern32", g, x2)
+    for it in range(4):
+        elbo, grad, info = engine.elbo_step(Y, yy, theta)
+        st = Kr.elbo_step(y.reshape(n, n), f1, f2, theta)
+        assert abs(elbo - st.elbo) <= RTOL * abs(st.elbo)
+        assert rel(grad, st.grad) < RTOL
+        theta = theta * (1 + 0.01 * np.array([1, -1, 0.5, -0.5, 1]))
+
+
+def test_split_partials_equal_step(engine):
+    """partials + finish with an externally owned payload == elbo_step (the multi-GPU seam)."""
+    case = CASES[2]
+    st, elbo, grad, info, _ = run_case(engine, *case)
+    X, y, x1, x2 = D.gen_grid(case[0], case[1])
+    Y = torch.tensor(y.reshape(case[1], case[0]), device=DEV)
+    pay = engine.elbo_partials(Y, case[6])
+    e2, g2, _ = engine.elbo_finish(pay, engine.sumsq(Y), case[6])
+    assert e2 == elbo and np.array_equal(g2, grad)

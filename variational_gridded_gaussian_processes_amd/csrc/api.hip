@@ -1,0 +1,707 @@
+// C-ABI of libvggp_hip.so (include/vggp.h): context, workspace arena and the launch sequence
+// of the ELBO step / q(v) / posterior.  Host logic only -- every number is produced by the HIP
+// kernels in factor_build.hip, chol.hip, gemm.hip, eigh.hip and mspace.hip.  There is no CPU
+// fallback: without a gfx950 device every entry point returns VGGP_EHIP.
+#include "common.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+// ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* vggp_last_error(void) { return g_err; }
+extern "C" int vggp_version(void) { return VGGP_VERSION; }
+
+struct VgDim {
+    int kind = 0, basis = 0, n = 0, m = 0;
+    double *x = nullptr, *grid = nullptr;
+    double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
+    double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
+    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr;
+    double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
+    double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
+    double2* rotlog = nullptr;
+    int *roundlog = nullptr, *counters = nullptr, *status = nullptr;
+    int gh_split = 1, max_rounds = 0;
+    bool have_prev = false;
+};
+
+struct HostOut {            // pinned readback block
+    double out[8];
+    double jitter[2];
+    int counters[2][4];
+    int status[2];
+};
+
+struct vggp_ctx {
+    int device = 0;
+    bool planned = false;
+    vggp_desc desc{};
+    VgDim d[2];
+    void* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    // cross-dimension buffers
+    double *St = nullptr, *CCslab = nullptr, *payload = nullptr, *GH1 = nullptr;
+    double *T3 = nullptr, *P3 = nullptr, *beta = nullptr, *bl2 = nullptr, *bl1 = nullptr, *invD = nullptr;
+    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
+    double *out = nullptr, *theta = nullptr, *wq = nullptr;
+    int st_split = 1, cc_split = 1;
+    long payload_len = 0;
+    bool have_partials = false, have_step = false;
+    // pinned host staging
+    double* h_theta = nullptr;
+    HostOut* h_out = nullptr;
+    // scratch for the exported building blocks / posterior (lazy)
+    void* misc = nullptr;
+    size_t misc_bytes = 0;
+    double* sumsq_partial = nullptr;
+    double* sumsq_out = nullptr;
+};
+
+static int ensure_misc(vggp_ctx* c, size_t bytes) {
+    if (c->misc_bytes >= bytes) return VGGP_OK;
+    if (c->misc) { VG_HIP(hipFree(c->misc)); c->misc = nullptr; c->misc_bytes = 0; }
+    VG_HIP(hipMalloc(&c->misc, bytes));
+    c->misc_bytes = bytes;
+    return VGGP_OK;
+}
+
+extern "C" int vggp_create(vggp_ctx** out, int device) {
+    if (!out) { vg_set_error("vggp_create: null out"); return VGGP_EINVAL; }
+    int ndev = 0;
+    VG_HIP(hipGetDeviceCount(&ndev));
+    VG_REQUIRE(device >= 0 && device < ndev, "vggp_create: device %d out of range (%d devices)", device, ndev);
+    VG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        vg_set_error("vggp_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return VGGP_EHIP;
+    }
+    VG_HIP(vg_chol_setup());
+    VG_HIP(vg_eigh_setup());
+    vggp_ctx* c = new (std::nothrow) vggp_ctx();
+    if (!c) { vg_set_error("out of host memory"); return VGGP_ENOMEM; }
+    c->device = device;
+    VG_HIP(hipHostMalloc((void**)&c->h_theta, 8 * sizeof(double), hipHostMallocDefault));
+    VG_HIP(hipHostMalloc((void**)&c->h_out, sizeof(HostOut), hipHostMallocDefault));
+    VG_HIP(hipMalloc((void**)&c->sumsq_partial, 1024 * sizeof(double)));
+    VG_HIP(hipMalloc((void**)&c->sumsq_out, 8 * sizeof(double)));
+    *out = c;
+    return VGGP_OK;
+}
+
+extern "C" int vggp_destroy(vggp_ctx* c) {
+    if (!c) return VGGP_OK;
+    hipSetDevice(c->device);
+    if (c->arena) hipFree(c->arena);
+    if (c->misc) hipFree(c->misc);
+    if (c->h_theta) hipHostFree(c->h_theta);
+    if (c->h_out) hipHostFree(c->h_out);
+    if (c->sumsq_partial) hipFree(c->sumsq_partial);
+    if (c->sumsq_out) hipFree(c->sumsq_out);
+    delete c;
+    return VGGP_OK;
+}
+
+// bump allocator over the arena (256-B aligned)
+struct Bump {
+    char* base;
+    size_t off = 0;
+    bool dry;
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + 255) & ~size_t(255);
+        T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+static int pick_split(int tiles, int K, int target) {
+    int s = (target + tiles - 1) / tiles;
+    int maxs = std::max(1, K / (4 * VG_BK));
+    return std::max(1, std::min(s, maxs));
+}
+
+static void layout(vggp_ctx* c, Bump& b) {
+    const vggp_desc& D = c->desc;
+    const long n1 = D.n1, n2 = D.n2, m1 = D.m1, m2 = D.m2;
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const long m = d.m, n = d.n, m2e = m + (m & 1);
+        const int glen = d.basis == VGGP_BASIS_B0 ? m + 1 : m;
+        d.x = b.take<double>(n);
+        d.grid = b.take<double>(glen);
+        d.K0 = b.take<double>(m * m);
+        d.dK0 = b.take<double>(m * m);
+        d.AD = b.take<double>(2 * m * n);
+        d.L0 = b.take<double>(m * m);
+        d.Linv0 = b.take<double>(m * m);
+        d.BV = b.take<double>(2 * m * n);
+        d.X = b.take<double>(m * m);
+        d.Mk = b.take<double>(m * m);
+        d.GH = b.take<double>(2 * m * m);
+        d.gh_split = pick_split((int)(((m + 63) / 64) * ((m + 63) / 64)), (int)n, 32);
+        d.GHslab = b.take<double>((size_t)d.gh_split * 2 * m * m);
+        d.Gw = b.take<double>(m * m);
+        d.lam0 = b.take<double>(m);
+        d.Qt = b.take<double>(m * m);
+        d.QtPrev = b.take<double>(m * m);
+        d.TM = b.take<double>(m * m);
+        d.TH = b.take<double>(m * m);
+        d.E = b.take<double>(m * m);
+        d.F = b.take<double>(m * m);
+        d.RQ = b.take<double>(m * m);
+        d.RQsq = b.take<double>(m * m);
+        d.chol_scratch = b.take<double>(m * (m + 1));
+        d.gwork = b.take<double>(m2e * (m2e + 1));
+        d.jitter = b.take<double>(2);
+        d.max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
+        d.rotlog = b.take<double2>((size_t)d.max_rounds * (m2e / 2));
+        d.roundlog = b.take<int>(d.max_rounds);
+        d.counters = b.take<int>(4);
+        d.status = b.take<int>(2);
+    }
+    const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
+    c->st_split = pick_split(st_tiles, (int)n2, 256);
+    c->St = b.take<double>((size_t)c->st_split * 2 * m2 * n1);
+    const int cc_tiles = (int)(((2 * m1 + 63) / 64) * ((m2 + 63) / 64));
+    c->cc_split = pick_split(cc_tiles, (int)n1, 64);
+    c->CCslab = b.take<double>((size_t)c->cc_split * 3 * m1 * m2);
+    c->payload_len = 2 * m2 * m2 + 3 * m1 * m2;
+    c->payload = b.take<double>(c->payload_len);
+    c->T3 = b.take<double>(3 * m1 * m2);
+    c->P3 = b.take<double>(3 * m1 * m2);
+    c->beta = b.take<double>(m1 * m2);
+    c->bl2 = b.take<double>(m1 * m2);
+    c->bl1 = b.take<double>(m1 * m2);
+    c->invD = b.take<double>(m1 * m2);
+    c->rowpart = b.take<double>(m1 * 8);
+    c->r1 = b.take<double>(m1);
+    c->r1l = b.take<double>(m1);
+    c->X1 = b.take<double>(m1 * m1);
+    c->X1l = b.take<double>(m1 * m1);
+    c->X2 = b.take<double>(m2 * m2);
+    c->X2l = b.take<double>(m2 * m2);
+    c->wq = b.take<double>(2 * m1 * m2);
+    c->out = b.take<double>(8);
+    c->theta = b.take<double>(8);
+}
+
+static int check_dim(int kind, int basis, long n, long m, const char* which) {
+    VG_REQUIRE(kind >= 0 && kind <= 3, "vggp_plan: bad kind for %s", which);
+    VG_REQUIRE(basis >= 0 && basis <= 2, "vggp_plan: bad basis for %s", which);
+    VG_REQUIRE(!(basis == VGGP_BASIS_B0 && kind != VGGP_KIND_MATERN12),
+               "vggp_plan: the B0 basis exists for Matern-1/2 only (%s)", which);
+    VG_REQUIRE(n >= 1, "vggp_plan: %s has no observations", which);
+    VG_REQUIRE(m >= 1 && m <= 512, "vggp_plan: m=%ld for %s outside [1, 512]", m, which);
+    VG_REQUIRE(!(basis == VGGP_BASIS_ONE && m != 1), "vggp_plan: BASIS_ONE needs m=1 (%s)", which);
+    return VGGP_OK;
+}
+
+extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
+    if (!c || !desc) { vg_set_error("vggp_plan: null argument"); return VGGP_EINVAL; }
+    VG_HIP(hipSetDevice(c->device));
+    int rc;
+    if ((rc = check_dim(desc->kind1, desc->basis1, desc->n1, desc->m1, "dimension 1"))) return rc;
+    if ((rc = check_dim(desc->kind2, desc->basis2, desc->n2, desc->m2, "dimension 2"))) return rc;
+    VG_REQUIRE(desc->x1 && desc->x2, "vggp_plan: null coordinate arrays");
+    VG_REQUIRE((desc->basis1 == VGGP_BASIS_ONE || desc->grid1) && (desc->basis2 == VGGP_BASIS_ONE || desc->grid2),
+               "vggp_plan: null grid arrays");
+    VG_REQUIRE(desc->n_total >= desc->n1 * desc->n2, "vggp_plan: n_total smaller than the local grid");
+    VG_REQUIRE(desc->n1 < (1L << 24) && desc->n2 < (1L << 24), "vggp_plan: grid axis too long");
+    c->planned = false;
+    c->desc = *desc;
+    c->d[0] = VgDim();
+    c->d[1] = VgDim();
+    c->d[0].kind = desc->kind1; c->d[0].basis = desc->basis1; c->d[0].n = (int)desc->n1; c->d[0].m = (int)desc->m1;
+    c->d[1].kind = desc->kind2; c->d[1].basis = desc->basis2; c->d[1].n = (int)desc->n2; c->d[1].m = (int)desc->m2;
+    Bump dry{nullptr, 0, true};
+    layout(c, dry);
+    const size_t need = dry.off + 4096;
+    if (need > c->arena_bytes) {
+        if (c->arena) { VG_HIP(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+        VG_HIP(hipMalloc(&c->arena, need));
+        c->arena_bytes = need;
+    }
+    Bump wet{reinterpret_cast<char*>(c->arena), 0, false};
+    layout(c, wet);
+    c->arena_used = wet.off;
+    VG_HIP(hipMemset(c->arena, 0, c->arena_used));
+    const double one = 1.0;
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const double* hx = k == 0 ? desc->x1 : desc->x2;
+        const double* hg = k == 0 ? desc->grid1 : desc->grid2;
+        VG_HIP(hipMemcpy(d.x, hx, sizeof(double) * d.n, hipMemcpyHostToDevice));
+        if (d.basis == VGGP_BASIS_ONE) {
+            VG_HIP(hipMemcpy(d.grid, &one, sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            const int glen = d.basis == VGGP_BASIS_B0 ? d.m + 1 : d.m;
+            VG_HIP(hipMemcpy(d.grid, hg, sizeof(double) * glen, hipMemcpyHostToDevice));
+        }
+    }
+    c->desc.x1 = c->desc.x2 = c->desc.grid1 = c->desc.grid2 = nullptr;   // host pointers not retained
+    c->have_partials = c->have_step = false;
+    c->planned = true;
+    return VGGP_OK;
+}
+
+extern "C" int64_t vggp_payload_len(const vggp_ctx* c) { return (c && c->planned) ? c->payload_len : 0; }
+extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t)c->arena_used : 0; }
+
+// ---------------------------------------------------------------------------------
+static int upload_theta(vggp_ctx* c, const double theta[5], hipStream_t st) {
+    for (int i = 0; i < 5; ++i) {
+        VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
+        c->h_theta[i] = theta[i];
+    }
+    VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double theta[5], double* payload, void* stream) {
+    if (!c || !c->planned) { vg_set_error("vggp_elbo_partials: context not planned"); return VGGP_ESTATE; }
+    VG_REQUIRE(Y && theta && payload, "vggp_elbo_partials: null argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = upload_theta(c, theta, st);
+    if (rc) return rc;
+    const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+
+    // 1. factor build (unit outputscale): A0|dA0, K0, dK0 for both dimensions
+    VgFactorJob fj[2];
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0};
+    }
+    VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
+
+    // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
+    VgCholJob cj[2];
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        VG_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), st));
+        cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
+    }
+    VG_HIP(vg_chol_launch(cj, 2, st));
+
+    // 3. B|V = Linv0 [A0|dA0],  X = Linv0 dK0
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const long mn = (long)d.m * d.n;
+        for (int b = 0; b < 2; ++b)
+            vg_gemm_add(&g, d.Linv0, d.m, 1, d.AD + b * mn, d.n, 1, d.BV + b * mn, d.n, d.m, d.n, d.m);
+        vg_gemm_add(&g, d.Linv0, d.m, 1, d.dK0, d.m, 1, d.X, d.m, d.m, d.m, d.m);
+    }
+    VG_HIP(vg_gemm_launch(&g, st));
+
+    // 4. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T, S^T = [B2;V2] Y (split-K slabs)
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
+        vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
+    }
+    vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    const int st_slabs = g.p[g.nprob - 1].ksplit;
+    const int gh_slabs[2] = {g.p[0].ksplit, g.p[2].ksplit};
+
+    // 5. [C;C1] = [B1;V1] S_B,  C2 = B1 S_V   (S^T slabs summed on load; split-K over n1)
+    vg_gemm_init(&g);
+    const long cc_slab = 3L * m1 * m2;
+    vg_gemm_add(&g, d1.BV, n1, 1, c->St, 1, n1, c->CCslab, (int)m2, (int)(2 * m1), (int)m2, (int)n1, c->cc_split, cc_slab,
+                st_slabs, 2L * m2 * n1);
+    vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
+                c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    const int cc_slabs = g.p[0].ksplit;
+
+    // 6. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}
+    VgRedBatch r;
+    vg_red_init(&r);
+    vg_red_add(&r, d1.GHslab, d1.GH, 2L * m1 * m1, 2L * m1 * m1, gh_slabs[0]);
+    vg_red_add(&r, d2.GHslab, payload, 2L * m2 * m2, 2L * m2 * m2, gh_slabs[1]);
+    vg_red_add(&r, c->CCslab, payload + 2 * m2 * m2, 3L * m1 * m2, cc_slab, cc_slabs);
+    VG_HIP(vg_red_launch(&r, st));
+    c->have_partials = true;
+    return VGGP_OK;
+}
+
+extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_total, const double theta[5],
+                                double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
+    if (!c || !c->planned || !c->have_partials) { vg_set_error("vggp_elbo_finish: call vggp_elbo_partials first"); return VGGP_ESTATE; }
+    VG_REQUIRE(payload && theta && elbo_out && grad_out, "vggp_elbo_finish: null argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = upload_theta(c, theta, st);
+    if (rc) return rc;
+    const long m1 = c->desc.m1, m2 = c->desc.m2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const double* G0[2] = {d1.GH, payload};
+    const double* H0[2] = {d1.GH + m1 * m1, payload + m2 * m2};
+    const double* C3 = payload + 2 * m2 * m2;
+    VgGemmBatch g;
+
+    // 7. eigendecompositions (optionally warm-started from the previous step's basis)
+    const bool warm = c->desc.warm_start && d1.have_prev && d2.have_prev;
+    VgEigJob ej[2];
+    if (warm) {
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m);
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.TM, d.m, 1, d.QtPrev, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+    }
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
+                         d.counters, d.m, d.max_rounds};
+    }
+    VG_HIP(vg_eigh_launch(ej, 2, st));
+
+    // 8. rotate into the eigenbasis: first the right factors ...
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, d.Mk, d.m, 1, d.Qt, 1, d.m, d.TM, d.m, d.m, d.m, d.m);      // Mk Q
+        vg_gemm_add(&g, H0[k], d.m, 1, d.Qt, 1, d.m, d.TH, d.m, d.m, d.m, d.m);     // H0 Q
+    }
+    vg_gemm_add(&g, C3, m2, 1, d2.Qt, 1, m2, c->T3, (int)m2, (int)(3 * m1), (int)m2, (int)m2);   // [C;C1;C2] Q2
+    VG_HIP(vg_gemm_launch(&g, st));
+    //    ... then the left factors
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, d.Qt, d.m, 1, d.TM, d.m, 1, d.E, d.m, d.m, d.m, d.m);       // E = Q^T Mk Q
+        vg_gemm_add(&g, d.Qt, d.m, 1, d.TH, d.m, 1, d.F, d.m, d.m, d.m, d.m);       // F = Q^T H0 Q
+    }
+    for (int q = 0; q < 3; ++q)
+        vg_gemm_add(&g, d1.Qt, m1, 1, c->T3 + q * m1 * m2, m2, 1, c->P3 + q * m1 * m2, (int)m2, (int)m1, (int)m2, (int)m1);
+    VG_HIP(vg_gemm_launch(&g, st));
+
+    // 9. D-stage, the four beta Gram matrices, final reduction
+    VgMspace ms;
+    ms.theta = c->theta; ms.lam1 = d1.lam0; ms.lam2 = d2.lam0; ms.P3 = c->P3;
+    ms.E1 = d1.E; ms.F1 = d1.F; ms.E2 = d2.E; ms.F2 = d2.F;
+    ms.X1 = c->X1; ms.X1l = c->X1l; ms.X2 = c->X2; ms.X2l = c->X2l;
+    ms.beta = c->beta; ms.bl2 = c->bl2; ms.bl1 = c->bl1; ms.invD = c->invD;
+    ms.rowpart = c->rowpart; ms.r1 = c->r1; ms.r1l = c->r1l; ms.out = c->out;
+    ms.m1 = (int)m1; ms.m2 = (int)m2; ms.n_total = (double)c->desc.n_total; ms.yy = yy_total;
+    VG_HIP(vg_dstage_launch(&ms, st));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, c->beta, m2, 1, c->beta, 1, m2, c->X1, (int)m1, (int)m1, (int)m1, (int)m2);    // beta beta^T
+    vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
+    vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
+    vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
+    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_final_launch(&ms, st));
+
+    // 10. the only host sync of the step: 6 doubles + diagnostics
+    VG_HIP(hipMemcpyAsync(c->h_out->out, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        VG_HIP(hipMemcpyAsync(&c->h_out->jitter[k], d.jitter, sizeof(double), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipMemcpyAsync(c->h_out->counters[k], d.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipMemcpyAsync(&c->h_out->status[k], d.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    VG_HIP(hipStreamSynchronize(st));
+    *elbo_out = c->h_out->out[0];
+    for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
+    int status = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (c->h_out->status[k]) status = c->h_out->status[k];
+        else if (c->h_out->counters[k][2]) status = c->h_out->counters[k][2];
+    }
+    if (info) {
+        info->jitter1 = c->h_out->jitter[0]; info->jitter2 = c->h_out->jitter[1];
+        info->sweeps1 = c->h_out->counters[0][1]; info->sweeps2 = c->h_out->counters[1][1];
+        info->rounds1 = c->h_out->counters[0][0]; info->rounds2 = c->h_out->counters[1][0];
+        info->status = status; info->reserved = 0;
+    }
+    if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
+    if (status == VGGP_ENOCONV) { vg_set_error("Jacobi eigensolver did not converge"); return VGGP_ENOCONV; }
+    // keep this step's basis for the next warm start
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        std::swap(d.Qt, d.QtPrev);      // QtPrev now holds the fresh basis; Qt is scratch until the next step
+        d.have_prev = true;
+    }
+    c->have_step = true;
+    return VGGP_OK;
+}
+
+extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
+                              double grad_out[5], vggp_info* info, void* stream) {
+    if (!c || !c->planned) { vg_set_error("vggp_elbo_step: context not planned"); return VGGP_ESTATE; }
+    int rc = vggp_elbo_partials(c, Y, theta, c->payload, stream);
+    if (rc) return rc;
+    return vggp_elbo_finish(c, c->payload, yy_total, theta, elbo_out, grad_out, info, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// q(v): mean = R1 (beta/v) R2^T, diag cov = (R1 o R1)(1/D)(R2 o R2)^T, R_d = sqrt(s_d) L0_d Q_d
+static int build_RQ(vggp_ctx* c, hipStream_t st) {
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, d.L0, d.m, 1, d.QtPrev, 1, d.m, d.RQ, d.m, d.m, d.m, d.m);   // L0 Q (QtPrev = last basis)
+    }
+    VG_HIP(vg_gemm_launch(&g, st));
+    for (int k = 0; k < 2; ++k) VG_HIP(vg_scale_sq_launch(c->d[k].RQ, c->d[k].RQsq, (long)c->d[k].m * c->d[k].m, st));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_qv(vggp_ctx* c, double* mean, double* var, void* stream) {
+    if (!c || !c->have_step) { vg_set_error("vggp_qv: no finished ELBO step"); return VGGP_ESTATE; }
+    VG_REQUIRE(mean && var, "vggp_qv: null output");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long m1 = c->desc.m1, m2 = c->desc.m2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    int rc = build_RQ(c, st);
+    if (rc) return rc;
+    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, st));
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, d1.RQ, m1, 1, c->wq, m2, 1, c->T3, (int)m2, (int)m1, (int)m2, (int)m1);
+    vg_gemm_add(&g, d1.RQsq, m1, 1, c->invD, m2, 1, c->T3 + m1 * m2, (int)m2, (int)m1, (int)m2, (int)m1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, c->T3, m2, 1, d2.RQ, 1, m2, mean, (int)m2, (int)m1, (int)m2, (int)m2);
+    vg_gemm_add(&g, c->T3 + m1 * m2, m2, 1, d2.RQsq, 1, m2, var, (int)m2, (int)m1, (int)m2, (int)m2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_scale_launch(var, m1 * m2, c->theta, 0, st));
+    return VGGP_OK;
+}
+
+__global__ void vg_kron_rows_kernel(const double* R1, const double* R2, const double* w, int m1, int m2, double* Rk,
+                                    double* Rs) {
+    // Rk[(a,b)][(i1,i2)] = R1[a][i1] R2[b][i2];  Rs = Rk * w[(i1,i2)]
+    const long M = (long)m1 * m2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    const long row = idx / M, col = idx - row * M;
+    const int a = (int)(row / m2), b = (int)(row - (long)a * m2);
+    const int i1 = (int)(col / m2), i2 = (int)(col - (long)i1 * m2);
+    const double v = R1[a * m1 + i1] * R2[b * m2 + i2];
+    Rk[idx] = v;
+    Rs[idx] = v * w[col];
+}
+
+extern "C" int vggp_qv_cov(vggp_ctx* c, double* cov, void* stream) {
+    if (!c || !c->have_step) { vg_set_error("vggp_qv_cov: no finished ELBO step"); return VGGP_ESTATE; }
+    VG_REQUIRE(cov, "vggp_qv_cov: null output");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long m1 = c->desc.m1, m2 = c->desc.m2, M = m1 * m2;
+    VG_REQUIRE(M <= 8192, "vggp_qv_cov: M=%ld too large for a dense covariance (use vggp_qv for mean/variance)", M);
+    int rc = build_RQ(c, st);
+    if (rc) return rc;
+    rc = ensure_misc(c, 2 * M * M * sizeof(double));
+    if (rc) return rc;
+    double* Rk = (double*)c->misc;
+    double* Rs = Rk + M * M;
+    hipLaunchKernelGGL(vg_kron_rows_kernel, dim3((unsigned)((M * M + 255) / 256)), dim3(256), 0, st, c->d[0].RQ,
+                       c->d[1].RQ, c->invD, (int)m1, (int)m2, Rk, Rs);
+    VG_HIP(hipGetLastError());
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, Rs, M, 1, Rk, 1, M, cov, (int)M, (int)M, (int)M, (int)M);
+    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_scale_launch(cov, M * M, c->theta, 0, st));
+    return VGGP_OK;
+}
+
+// posterior at scattered points, processed in chunks so the workspace stays bounded
+extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2, int64_t ns, double* mean, double* var,
+                              void* stream) {
+    if (!c || !c->have_step) { vg_set_error("vggp_posterior: no finished ELBO step"); return VGGP_ESTATE; }
+    VG_REQUIRE(xs1 && xs2 && mean && var && ns >= 0, "vggp_posterior: bad argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long m1 = c->desc.m1, m2 = c->desc.m2;
+    const long chunk = std::min<long>(ns, 8192);
+    if (ns == 0) return VGGP_OK;
+    // per chunk: A(m x c), B(m x c), T(m x c) for both dims, T2sq, U, Uv (m1 x c)
+    const size_t per = (size_t)chunk * (3 * m1 + 4 * m2 + 2 * m1);
+    int rc = ensure_misc(c, per * sizeof(double));
+    if (rc) return rc;
+    double* p = (double*)c->misc;
+    double* A1 = p; p += m1 * chunk;
+    double* B1 = p; p += m1 * chunk;
+    double* T1 = p; p += m1 * chunk;
+    double* A2 = p; p += m2 * chunk;
+    double* B2 = p; p += m2 * chunk;
+    double* T2 = p; p += m2 * chunk;
+    double* T2sq = p; p += m2 * chunk;
+    double* U = p; p += m1 * chunk;
+    double* Uv = p; p += m1 * chunk;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, st));   // wq = [beta rs / v | invD - 1]
+    for (long off = 0; off < ns; off += chunk) {
+        const int cn = (int)std::min<long>(chunk, ns - off);
+        VgFactorJob fj[2] = {
+            VgFactorJob{xs1 + off, d1.grid, A1, nullptr, nullptr, nullptr, cn, d1.m, d1.kind, d1.basis, 0, 0.0},
+            VgFactorJob{xs2 + off, d2.grid, A2, nullptr, nullptr, nullptr, cn, d2.m, d2.kind, d2.basis, 1, 0.0}};
+        VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
+        VgGemmBatch g;
+        vg_gemm_init(&g);
+        vg_gemm_add(&g, d1.Linv0, m1, 1, A1, cn, 1, B1, cn, (int)m1, cn, (int)m1);
+        vg_gemm_add(&g, d2.Linv0, m2, 1, A2, cn, 1, B2, cn, (int)m2, cn, (int)m2);
+        VG_HIP(vg_gemm_launch(&g, st));
+        vg_gemm_init(&g);
+        vg_gemm_add(&g, d1.QtPrev, m1, 1, B1, cn, 1, T1, cn, (int)m1, cn, (int)m1);
+        vg_gemm_add(&g, d2.QtPrev, m2, 1, B2, cn, 1, T2, cn, (int)m2, cn, (int)m2);
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_HIP(vg_scale_sq_launch(T2, T2sq, (long)m2 * cn, st));
+        vg_gemm_init(&g);
+        vg_gemm_add(&g, c->wq, m2, 1, T2, cn, 1, U, cn, (int)m1, cn, (int)m2);
+        vg_gemm_add(&g, c->wq + m1 * m2, m2, 1, T2sq, cn, 1, Uv, cn, (int)m1, cn, (int)m2);
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_HIP(vg_post_combine_launch(c->theta, T1, U, Uv, nullptr, (int)m1, (int)m2, cn, mean + off, var + off, st));
+    }
+    return VGGP_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// exported building blocks
+extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double* x, int64_t n, const double* grid,
+                                 int64_t m, double ell, double* A0, double* dA0, double* K0, double* dK0, void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(kind >= 0 && kind <= 3 && basis >= 0 && basis <= 2, "vggp_factor_build: bad kind/basis");
+    VG_REQUIRE(!(basis == VGGP_BASIS_B0 && kind != VGGP_KIND_MATERN12), "vggp_factor_build: B0 is Matern-1/2 only");
+    VG_REQUIRE(n >= 0 && m >= 1 && ell > 0.0, "vggp_factor_build: bad sizes / lengthscale");
+    VG_REQUIRE(grid || basis == VGGP_BASIS_ONE, "vggp_factor_build: null grid");
+    VG_REQUIRE((x || !(A0 || dA0)), "vggp_factor_build: null x");
+    VG_HIP(hipSetDevice(c->device));
+    VgFactorJob j{x, grid, n > 0 ? A0 : nullptr, n > 0 ? dA0 : nullptr, K0, dK0, (int)n, (int)m, kind, basis, -1, ell};
+    VG_HIP(vg_factor_build_launch(&j, 1, nullptr, (hipStream_t)stream));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, double* L, double* Linv, double* jitter_out,
+                                     void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(K && L && Linv && m >= 1 && m <= 1024, "vggp_cholesky_inverse: bad argument (1 <= m <= 1024)");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_misc(c, (size_t)(m * (m + 1) + 16) * sizeof(double));
+    if (rc) return rc;
+    double* scratch = (double*)c->misc;
+    double* jit = scratch + m * (m + 1);
+    int* status = (int*)(jit + 2);
+    VG_HIP(hipMemsetAsync(jit, 0, 8 * sizeof(double), st));
+    VgCholJob j{K, L, Linv, scratch, jit, status, (int)m};
+    VG_HIP(vg_chol_launch(&j, 1, st));
+    double hj = 0.0;
+    int hs = 0;
+    VG_HIP(hipMemcpyAsync(&hj, jit, sizeof(double), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipMemcpyAsync(&hs, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    if (jitter_out) *jitter_out = hj;
+    if (hs) { vg_set_error("vggp_cholesky_inverse: not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
+    return VGGP_OK;
+}
+
+extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, double* Qt, int32_t* sweeps_out, void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(G && lam && Qt && m >= 1 && m <= 512, "vggp_eigh: bad argument (1 <= m <= 512)");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long m2e = m + (m & 1);
+    const int max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
+    const size_t need = (size_t)m2e * (m2e + 1) * 8 + (size_t)max_rounds * (m2e / 2) * 16 + (size_t)max_rounds * 4 + 256;
+    int rc = ensure_misc(c, need);
+    if (rc) return rc;
+    char* p = (char*)c->misc;
+    double* gwork = (double*)p; p += (size_t)m2e * (m2e + 1) * 8;
+    double2* rotlog = (double2*)p; p += (size_t)max_rounds * (m2e / 2) * 16;
+    int* roundlog = (int*)p; p += (size_t)max_rounds * 4;
+    p = (char*)(((uintptr_t)p + 63) & ~uintptr_t(63));
+    int* counters = (int*)p;
+    VG_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+    VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds};
+    VG_HIP(vg_eigh_launch(&j, 1, st));
+    int hc[4] = {0, 0, 0, 0};
+    VG_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    if (sweeps_out) *sweeps_out = hc[1];
+    if (hc[2]) { vg_set_error("vggp_eigh: no convergence"); return VGGP_ENOCONV; }
+    return VGGP_OK;
+}
+
+extern "C" int vggp_gemm(vggp_ctx* c, const double* A, int64_t sa_m, int64_t sa_k, const double* B, int64_t sb_k,
+                         int64_t sb_n, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N, "vggp_gemm: bad argument");
+    VG_REQUIRE(M < (1L << 30) && N < (1L << 30) && K < (1L << 30), "vggp_gemm: dimension too large");
+    VG_HIP(hipSetDevice(c->device));
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, A, sa_m, sa_k, B, sb_k, sb_n, C, (int)ldc, (int)M, (int)N, (int)K);
+    VG_HIP(vg_gemm_launch(&g, (hipStream_t)stream));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, const double* L2inv, int64_t n2,
+                               const double* Y, double* X, void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(L1inv && L2inv && Y && X && n1 >= 1 && n2 >= 1, "vggp_kron_solve: bad argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_misc(c, 2 * (size_t)n1 * n2 * sizeof(double));
+    if (rc) return rc;
+    double* T1 = (double*)c->misc;
+    double* T2 = T1 + n1 * n2;
+    VgGemmBatch g;
+    // X = L1^{-T} ( L1^{-1} Y L2^{-T} ) L2^{-1}
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, L1inv, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1);        // L1inv Y
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, T1, n2, 1, L2inv, 1, n2, T2, (int)n2, (int)n1, (int)n2, (int)n2);       // . L2inv^T
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, L1inv, 1, n1, T2, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1);       // L1inv^T .
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, T1, n2, 1, L2inv, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2);        // . L2inv
+    VG_HIP(vg_gemm_launch(&g, st));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_sumsq(vggp_ctx* c, const double* y, int64_t n, double* out, void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(y && out && n >= 0, "vggp_sumsq: bad argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    VG_HIP(vg_sumsq_launch(y, n, c->sumsq_partial, c->sumsq_out, st));
+    VG_HIP(hipMemcpyAsync(out, c->sumsq_out, sizeof(double), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}

@@ -1,0 +1,156 @@
+// Shared declarations for the libvggp_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vggp.h"
+
+#define VG_WAVE 64
+
+// ---- error plumbing (never throw across the C boundary) -----------------------
+void vg_set_error(const char* fmt, ...);
+#define VG_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t _e = (call);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            vg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,            \
+                         hipGetErrorString(_e));                                  \
+            return VGGP_EHIP;                                                     \
+        }                                                                         \
+    } while (0)
+#define VG_REQUIRE(cond, ...)                                                     \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            vg_set_error(__VA_ARGS__);                                            \
+            return VGGP_EINVAL;                                                   \
+        }                                                                         \
+    } while (0)
+
+// ---- batched strided GEMM descriptors (passed by value as kernel argument) -----
+#define VG_GEMM_MAXP 8
+#define VG_BM 64
+#define VG_BN 64
+#define VG_BK 16
+
+struct VgGemmP {
+    const double* A;   // element (i,k) at A[i*sa_m + k*sa_k]
+    const double* B;   // element (k,j) at B[k*sb_k + j*sb_n]
+    double* C;         // row-major, leading dim ldc; split-K slab s at C + s*c_slab
+    long sa_m, sa_k, sb_k, sb_n;
+    long c_slab;       // doubles between split-K output slabs
+    long b_slab;       // B operand = sum of b_nslab slabs, this many doubles apart
+    int M, N, K;
+    int ldc;
+    int ksplit;        // >= 1
+    int b_nslab;       // >= 1
+    int tiles_m, tiles_n;
+    int tile_start;    // first linear block index of this problem
+    int kchunk;        // K elements per split (multiple of VG_BK)
+};
+struct VgGemmBatch {
+    int nprob;
+    int total_tiles;
+    VgGemmP p[VG_GEMM_MAXP];
+};
+
+// host helpers (gemm.hip)
+void vg_gemm_init(VgGemmBatch* b);
+// append one problem; returns index.  ksplit slabs land at C + s*c_slab.
+int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const double* B, long sb_k,
+                long sb_n, double* C, int ldc, int M, int N, int K, int ksplit = 1, long c_slab = 0,
+                int b_nslab = 1, long b_slab = 0);
+hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st);
+
+// segment reduction: out[i] = sum_s in[s*slab + i]
+#define VG_RED_MAXSEG 8
+struct VgRedSeg { const double* in; double* out; long n; long slab; int nslab; int block_start; };
+struct VgRedBatch { int nseg; int total_blocks; VgRedSeg s[VG_RED_MAXSEG]; };
+void vg_red_init(VgRedBatch* b);
+void vg_red_add(VgRedBatch* b, const double* in, double* out, long n, long slab, int nslab);
+hipError_t vg_red_launch(const VgRedBatch* b, hipStream_t st);
+
+// ---- factor build (factor_build.hip) ------------------------------------------
+struct VgFactorJob {
+    const double* x;      // [n] observation coordinates (device)
+    const double* grid;   // mesh [m+1] or inducing coords [m] (device)
+    double* A0;           // [m][n]   (may be null)
+    double* dA0;          // [m][n]
+    double* K0;           // [m][m]   (may be null)
+    double* dK0;          // [m][m]
+    int n, m, kind, basis;
+    int theta_idx;        // index of ell in the device theta vector, or -1 -> use ell_imm
+    double ell_imm;
+};
+hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const double* theta_dev,
+                                  hipStream_t st);
+
+// ---- Cholesky + explicit inverse (chol.hip) ------------------------------------
+struct VgCholJob {
+    const double* K;      // [m][m]
+    double* L;            // [m][m] lower, zero above
+    double* Linv;         // [m][m] lower, zero above
+    double* scratch;      // [m][m+1] global work area (used when m does not fit LDS)
+    double* jitter_out;   // device scalar
+    int* status;          // device int (0 ok, VGGP_ENOTPD)
+    int m;
+};
+hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_chol_setup();   // opt-in to large dynamic LDS
+
+// ---- Jacobi eigensolver (eigh.hip) ---------------------------------------------
+#define VG_EIG_MAXSWEEP 60
+struct VgEigJob {
+    const double* G;      // [m][m] symmetric
+    double* lam;          // [m]
+    double* Qt;           // [m][m], row j = eigenvector j
+    const double* Qt0;    // optional start basis (warm start): G is then Qt0 G Qt0^T already
+    double* gwork;        // [m2][m2+1] global G work area when it does not fit LDS
+    double2* rotlog;      // [max_rounds][m2/2] (c,s)
+    int* roundlog;        // [max_rounds] round index r of each logged round
+    int* counters;        // [4]: nlog, sweeps, status, pad
+    int m;
+    int max_rounds;
+};
+hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_eigh_setup();
+
+// ---- m-space elementwise / reductions (mspace.hip) -----------------------------
+struct VgMspace {
+    // inputs
+    const double* theta;     // device [5]
+    const double* lam1;      // unit-scale eigenvalues [m1]
+    const double* lam2;      // [m2]
+    const double* P3;        // [3][m1][m2] unit-scale P0, P1_0, P2_0
+    const double* E1;        // [m1][m1]  Q1^T Mk1 Q1
+    const double* F1;        // [m1][m1]  Q1^T H0_1 Q1 (unsymmetrised, unit scale)
+    const double* E2;
+    const double* F2;
+    const double* X1;        // beta beta^T           [m1][m1]
+    const double* X1l;       // (beta lam2) beta^T    [m1][m1]
+    const double* X2;        // beta^T beta           [m2][m2]
+    const double* X2l;       // (beta lam1)^T beta    [m2][m2]
+    // produced by dstage
+    double* beta;            // [m1][m2]
+    double* bl2;             // beta * lam2[None,:]
+    double* bl1;             // beta * lam1[:,None]
+    double* invD;            // [m1][m2]
+    double* rowpart;         // [m1][8] per-row partial scalars
+    double* r1;              // [m1] sum_i2 1/D
+    double* r1l;             // [m1] sum_i2 lam2/D
+    // outputs
+    double* out;             // [8]: elbo, g_ell1, g_ell2, g_s1, g_s2, g_v, -, -
+    int m1, m2;
+    double n_total;
+    double yy;
+};
+hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st);
+hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st);
+
+// q(v) / posterior helpers
+hipError_t vg_scale_sq_launch(const double* in, double* out_sq, long n, hipStream_t st);
+hipError_t vg_qv_weights_launch(const double* theta, const double* beta, const double* invD, double* w_mean,
+                                long n, hipStream_t st);
+hipError_t vg_sumsq_launch(const double* y, long n, double* partial, double* out, hipStream_t st);
+hipError_t vg_post_combine_launch(const double* theta, const double* T1, const double* T2, const double* beta,
+                                  const double* invD, int m1, int m2, long ns, double* mean, double* var,
+                                  hipStream_t st);
+hipError_t vg_scale_launch(double* x, long n, const double* theta, int mode, hipStream_t st);

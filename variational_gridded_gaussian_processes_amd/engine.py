@@ -1,0 +1,199 @@
+"""Thin host wrapper over the C-ABI: one `Engine` = one vggp_ctx on one GPU.
+
+PyTorch is used only as the array container (device memory, streams); every number comes out
+of libvggp_hip.so.  All tensors handed to the engine must be CUDA(ROCm) float64 and contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BASIS, KIND, Desc, Info, check
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise TypeError("engine tensors must be contiguous float64 on the GPU")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dvec(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+
+
+class Engine:
+    """Owns a vggp_ctx.  See include/vggp.h for the contract of every call."""
+
+    def __init__(self, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("variational_gridded_gaussian_processes_amd needs a gfx950 GPU: "
+                               "torch.cuda.is_available() is False and there is no CPU path")
+        self.lib = _lib.load()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        check(self.lib.vggp_create(C.byref(h), self.device_index))
+        self._h = h
+        self.m1 = self.m2 = self.n1 = self.n2 = 0
+        self.planned = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vggp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- planning -------------------------------------------------------------------------------
+    def plan(self, kind1: str, basis1: str, grid1, x1, kind2: str, basis2: str, grid2, x2,
+             n_total: Optional[int] = None, warm_start: bool = False) -> None:
+        """grid_d: mesh (m+1 knots, basis 'b0') or inducing coordinates (m, basis 'points');
+        x_d: the n_d unique (local) observation coordinates along dimension d."""
+        x1, x2 = _dvec(x1), _dvec(x2)
+        g1 = _dvec(grid1) if basis1 != "one" else np.ones(1)
+        g2 = _dvec(grid2) if basis2 != "one" else np.ones(1)
+        m1 = 1 if basis1 == "one" else (len(g1) - 1 if basis1 == "b0" else len(g1))
+        m2 = 1 if basis2 == "one" else (len(g2) - 1 if basis2 == "b0" else len(g2))
+        d = Desc()
+        d.kind1, d.basis1, d.kind2, d.basis2 = KIND[kind1], BASIS[basis1], KIND[kind2], BASIS[basis2]
+        d.n1, d.n2, d.m1, d.m2 = len(x1), len(x2), m1, m2
+        d.n_total = int(n_total) if n_total is not None else len(x1) * len(x2)
+        d.x1, d.x2 = x1.ctypes.data, x2.ctypes.data
+        d.grid1, d.grid2 = g1.ctypes.data, g2.ctypes.data
+        d.warm_start = 1 if warm_start else 0
+        with torch.cuda.device(self.device):
+            check(self.lib.vggp_plan(self._h, C.byref(d)))
+        self.m1, self.m2, self.n1, self.n2 = m1, m2, len(x1), len(x2)
+        self.payload_len = int(self.lib.vggp_payload_len(self._h))
+        self.planned = True
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.vggp_workspace_bytes(self._h))
+
+    # -- hot path ---------------------------------------------------------------------------------
+    def _check_Y(self, Y: torch.Tensor):
+        if tuple(Y.shape) != (self.n2, self.n1):
+            raise ValueError(f"Y must be [n2={self.n2}, n1={self.n1}] (x1 fastest), got {tuple(Y.shape)}")
+
+    def elbo_step(self, Y: torch.Tensor, yy_total: float, theta: Sequence[float]):
+        """-> (elbo, grad[5] wrt (ell1, ell2, s1, s2, sigma2), info dict)."""
+        self._check_Y(Y)
+        th = (C.c_double * 5)(*[float(t) for t in theta])
+        elbo = C.c_double()
+        grad = (C.c_double * 5)()
+        info = Info()
+        check(self.lib.vggp_elbo_step(self._h, _ptr(Y), float(yy_total), th, C.byref(elbo), grad, C.byref(info),
+                                      _stream()))
+        return elbo.value, np.array(list(grad)), self._info(info)
+
+    def elbo_partials(self, Y: torch.Tensor, theta: Sequence[float], payload: Optional[torch.Tensor] = None):
+        self._check_Y(Y)
+        if payload is None:
+            payload = torch.empty(self.payload_len, dtype=torch.float64, device=self.device)
+        th = (C.c_double * 5)(*[float(t) for t in theta])
+        check(self.lib.vggp_elbo_partials(self._h, _ptr(Y), th, _ptr(payload), _stream()))
+        return payload
+
+    def elbo_finish(self, payload: torch.Tensor, yy_total: float, theta: Sequence[float]):
+        th = (C.c_double * 5)(*[float(t) for t in theta])
+        elbo = C.c_double()
+        grad = (C.c_double * 5)()
+        info = Info()
+        check(self.lib.vggp_elbo_finish(self._h, _ptr(payload), float(yy_total), th, C.byref(elbo), grad,
+                                        C.byref(info), _stream()))
+        return elbo.value, np.array(list(grad)), self._info(info)
+
+    @staticmethod
+    def _info(i: Info) -> dict:
+        return dict(jitter=(i.jitter1, i.jitter2), sweeps=(i.sweeps1, i.sweeps2), rounds=(i.rounds1, i.rounds2),
+                    status=i.status)
+
+    def qv(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        mean = torch.empty(self.m1, self.m2, dtype=torch.float64, device=self.device)
+        var = torch.empty_like(mean)
+        check(self.lib.vggp_qv(self._h, _ptr(mean), _ptr(var), _stream()))
+        return mean, var
+
+    def qv_cov(self) -> torch.Tensor:
+        M = self.m1 * self.m2
+        cov = torch.empty(M, M, dtype=torch.float64, device=self.device)
+        check(self.lib.vggp_qv_cov(self._h, _ptr(cov), _stream()))
+        return cov
+
+    def posterior(self, x_star: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """x_star [ns, 2] (or [ns] with a trivial second dimension) -> mean[ns], var[ns]."""
+        xs = x_star.to(self.device, torch.float64)
+        if xs.dim() == 1:
+            xs = torch.stack([xs, torch.zeros_like(xs)], dim=1)
+        xs1, xs2 = xs[:, 0].contiguous(), xs[:, 1].contiguous()
+        ns = xs1.shape[0]
+        mean = torch.empty(ns, dtype=torch.float64, device=self.device)
+        var = torch.empty_like(mean)
+        check(self.lib.vggp_posterior(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(mean), _ptr(var), _stream()))
+        return mean, var
+
+    # -- building blocks ------------------------------------------------------------------------------
+    def factor_build(self, kind: str, basis: str, x: torch.Tensor, grid: torch.Tensor, ell: float):
+        """-> A0[m,n], dA0[m,n], K0[m,m], dK0[m,m] at unit outputscale."""
+        n = x.shape[0]
+        m = 1 if basis == "one" else (grid.shape[0] - 1 if basis == "b0" else grid.shape[0])
+        o = dict(dtype=torch.float64, device=self.device)
+        A, dA, K, dK = torch.empty(m, n, **o), torch.empty(m, n, **o), torch.empty(m, m, **o), torch.empty(m, m, **o)
+        check(self.lib.vggp_factor_build(self._h, KIND[kind], BASIS[basis], _ptr(x), n, _ptr(grid), m, float(ell),
+                                         _ptr(A), _ptr(dA), _ptr(K), _ptr(dK), _stream()))
+        return A, dA, K, dK
+
+    def cholesky_inverse(self, K: torch.Tensor):
+        m = K.shape[0]
+        L, Li = torch.empty_like(K), torch.empty_like(K)
+        jit = C.c_double()
+        check(self.lib.vggp_cholesky_inverse(self._h, _ptr(K), m, _ptr(L), _ptr(Li), C.byref(jit), _stream()))
+        return L, Li, jit.value
+
+    def eigh(self, G: torch.Tensor):
+        """-> lam[m], Qt[m,m] (row j = eigenvector j), sweeps."""
+        m = G.shape[0]
+        lam = torch.empty(m, dtype=torch.float64, device=self.device)
+        Qt = torch.empty_like(G)
+        sw = C.c_int32()
+        check(self.lib.vggp_eigh(self._h, _ptr(G), m, _ptr(lam), _ptr(Qt), C.byref(sw), _stream()))
+        return lam, Qt, sw.value
+
+    def gemm(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """C = A @ B for 2-D float64 GPU tensors with arbitrary strides (no copies are made)."""
+        M, K = A.shape
+        K2, N = B.shape
+        assert K == K2
+        Cm = torch.empty(M, N, dtype=torch.float64, device=self.device)
+        for t in (A, B):
+            if not (t.is_cuda and t.dtype == torch.float64):
+                raise TypeError("gemm operands must be float64 GPU tensors")
+        check(self.lib.vggp_gemm(self._h, A.data_ptr(), A.stride(0), A.stride(1), B.data_ptr(), B.stride(0),
+                                 B.stride(1), Cm.data_ptr(), N, M, N, K, _stream()))
+        return Cm
+
+    def kron_solve(self, L1inv: torch.Tensor, L2inv: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        n1, n2 = Y.shape
+        X = torch.empty_like(Y)
+        check(self.lib.vggp_kron_solve(self._h, _ptr(L1inv), n1, _ptr(L2inv), n2, _ptr(Y), _ptr(X), _stream()))
+        return X
+
+    def sumsq(self, y: torch.Tensor) -> float:
+        out = C.c_double()
+        check(self.lib.vggp_sumsq(self._h, _ptr(y), y.numel(), C.byref(out), _stream()))
+        return out.value
