@@ -166,6 +166,14 @@ int vggp_gemm(vggp_ctx* ctx, const double* A, int64_t sa_m, int64_t sa_k,
 int vggp_kron_solve(vggp_ctx* ctx, const double* L1inv, int64_t n1, const double* L2inv, int64_t n2,
                     const double* Y, double* X, void* stream);
 
+/* Per-stage timing with HIP events on the stream the kernels are launched on (bench.py's
+ * live roofline measurement).  When enabled, every ELBO step records one event after each
+ * launch group; vggp_profile_read returns the accumulated milliseconds per stage. */
+#define VGGP_NSTAGE 14
+int         vggp_profile(vggp_ctx* ctx, int enable);
+int         vggp_profile_read(vggp_ctx* ctx, double ms_out[VGGP_NSTAGE], int32_t* steps_out, int reset);
+const char* vggp_stage_name(int stage);
+
 /* sum of squares of a DEVICE array (for yy_total); result to HOST. */
 int vggp_sumsq(vggp_ctx* ctx, const double* y, int64_t n, double* out, void* stream);
 

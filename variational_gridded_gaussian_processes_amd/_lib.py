@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(HERE, "libvggp_hip.so")
 
 VGGP_OK, VGGP_EINVAL, VGGP_ENOTPD, VGGP_EHIP, VGGP_ENOMEM, VGGP_ESTATE, VGGP_ENOCONV = 0, -1, -2, -3, -4, -5, -6
 KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
+NSTAGE = 14
 BASIS = {"points": 0, "b0": 1, "one": 2}
 
 
@@ -56,6 +57,9 @@ SYMBOLS = {
     "vggp_gemm": (_I, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "vggp_kron_solve": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "vggp_sumsq": (_I, [_P, _P, _I64, C.POINTER(_D), _P]),
+    "vggp_profile": (_I, [_P, _I]),
+    "vggp_profile_read": (_I, [_P, C.POINTER(_D), C.POINTER(C.c_int32), _I]),
+    "vggp_stage_name": (C.c_char_p, [_I]),
 }
 
 _lib = None

@@ -67,7 +67,25 @@ struct vggp_ctx {
     size_t misc_bytes = 0;
     double* sumsq_partial = nullptr;
     double* sumsq_out = nullptr;
+    // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
+    bool prof = false;
+    hipEvent_t ev[VGGP_NSTAGE + 2] = {};
+    bool ev_set[VGGP_NSTAGE + 2] = {};
+    double prof_ms[VGGP_NSTAGE] = {};
+    int prof_steps = 0;
 };
+
+static const char* VG_STAGE_NAMES[VGGP_NSTAGE] = {
+    "factor_build", "cholesky_inverse", "gemm_BV(Linv*[A|dA])", "gemm_gram+project(S=[B2;V2]Y)", "gemm_C(B1*S)",
+    "reduce_slabs", "gemm_warm_start", "jacobi_eigh", "jacobi_replay", "gemm_rotate_right", "gemm_rotate_left",
+    "dstage", "gemm_betaGram", "final_reduce"};
+extern "C" const char* vggp_stage_name(int i) { return (i >= 0 && i < VGGP_NSTAGE) ? VG_STAGE_NAMES[i] : ""; }
+
+// record event `slot` (slot 0 = start of partials, slot k = after stage k-1; slot 7 doubles as start of finish)
+#define VG_MARK(slot)                                                   \
+    do {                                                                \
+        if (c->prof) { VG_HIP(hipEventRecord(c->ev[slot], st)); c->ev_set[slot] = true; } \
+    } while (0)
 
 static int ensure_misc(vggp_ctx* c, size_t bytes) {
     if (c->misc_bytes >= bytes) return VGGP_OK;
@@ -281,6 +299,8 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     if (rc) return rc;
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
+    if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
+    VG_MARK(0);
 
     // 1. factor build (unit outputscale): A0|dA0, K0, dK0 for both dimensions
     VgFactorJob fj[2];
@@ -289,6 +309,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
         fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0};
     }
     VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
+    VG_MARK(1);
 
     // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
     VgCholJob cj[2];
@@ -298,6 +319,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
         cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
     }
     VG_HIP(vg_chol_launch(cj, 2, st));
+    VG_MARK(2);
 
     // 3. B|V = Linv0 [A0|dA0],  X = Linv0 dK0
     VgGemmBatch g;
@@ -310,6 +332,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
         vg_gemm_add(&g, d.Linv0, d.m, 1, d.dK0, d.m, 1, d.X, d.m, d.m, d.m, d.m);
     }
     VG_HIP(vg_gemm_launch(&g, st));
+    VG_MARK(3);
 
     // 4. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T, S^T = [B2;V2] Y (split-K slabs)
     vg_gemm_init(&g);
@@ -320,6 +343,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     }
     vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
     VG_HIP(vg_gemm_launch(&g, st));
+    VG_MARK(4);
     const int st_slabs = g.p[g.nprob - 1].ksplit;
     const int gh_slabs[2] = {g.p[0].ksplit, g.p[2].ksplit};
 
@@ -331,6 +355,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
                 c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
     VG_HIP(vg_gemm_launch(&g, st));
+    VG_MARK(5);
     const int cc_slabs = g.p[0].ksplit;
 
     // 6. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}
@@ -340,6 +365,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     vg_red_add(&r, d2.GHslab, payload, 2L * m2 * m2, 2L * m2 * m2, gh_slabs[1]);
     vg_red_add(&r, c->CCslab, payload + 2 * m2 * m2, 3L * m1 * m2, cc_slab, cc_slabs);
     VG_HIP(vg_red_launch(&r, st));
+    VG_MARK(6);
     c->have_partials = true;
     return VGGP_OK;
 }
@@ -360,6 +386,7 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     VgGemmBatch g;
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
+    VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
     const bool warm = c->desc.warm_start && d1.have_prev && d2.have_prev;
     VgEigJob ej[2];
     if (warm) {
@@ -376,12 +403,15 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
         }
         VG_HIP(vg_gemm_launch(&g, st));
     }
+    VG_MARK(7);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds};
     }
-    VG_HIP(vg_eigh_launch(ej, 2, st));
+    VG_HIP(vg_eigh_launch(ej, 2, st, c->prof ? c->ev[8] : nullptr));
+    if (c->prof) c->ev_set[8] = true;
+    VG_MARK(9);
 
     // 8. rotate into the eigenbasis: first the right factors ...
     vg_gemm_init(&g);
@@ -392,6 +422,7 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     }
     vg_gemm_add(&g, C3, m2, 1, d2.Qt, 1, m2, c->T3, (int)m2, (int)(3 * m1), (int)m2, (int)m2);   // [C;C1;C2] Q2
     VG_HIP(vg_gemm_launch(&g, st));
+    VG_MARK(10);
     //    ... then the left factors
     vg_gemm_init(&g);
     for (int k = 0; k < 2; ++k) {
@@ -402,6 +433,7 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     for (int q = 0; q < 3; ++q)
         vg_gemm_add(&g, d1.Qt, m1, 1, c->T3 + q * m1 * m2, m2, 1, c->P3 + q * m1 * m2, (int)m2, (int)m1, (int)m2, (int)m1);
     VG_HIP(vg_gemm_launch(&g, st));
+    VG_MARK(11);
 
     // 9. D-stage, the four beta Gram matrices, final reduction
     VgMspace ms;
@@ -412,13 +444,16 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     ms.rowpart = c->rowpart; ms.r1 = c->r1; ms.r1l = c->r1l; ms.out = c->out;
     ms.m1 = (int)m1; ms.m2 = (int)m2; ms.n_total = (double)c->desc.n_total; ms.yy = yy_total;
     VG_HIP(vg_dstage_launch(&ms, st));
+    VG_MARK(12);
     vg_gemm_init(&g);
     vg_gemm_add(&g, c->beta, m2, 1, c->beta, 1, m2, c->X1, (int)m1, (int)m1, (int)m1, (int)m2);    // beta beta^T
     vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
     vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
     vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
     VG_HIP(vg_gemm_launch(&g, st));
+    VG_MARK(13);
     VG_HIP(vg_final_launch(&ms, st));
+    VG_MARK(14);
 
     // 10. the only host sync of the step: 6 doubles + diagnostics
     VG_HIP(hipMemcpyAsync(c->h_out->out, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -429,6 +464,15 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
         VG_HIP(hipMemcpyAsync(&c->h_out->status[k], d.status, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     VG_HIP(hipStreamSynchronize(st));
+    if (c->prof && c->ev_set[0] && c->ev_set[14]) {
+        // stage i spans event slot i -> i+1, except stage 6 (warm-start GEMMs) which starts at the finish marker
+        for (int i = 0; i < VGGP_NSTAGE; ++i) {
+            const int a = (i == 6) ? VGGP_NSTAGE + 1 : i, b = i + 1;
+            float ms = 0.f;
+            if (c->ev_set[a] && c->ev_set[b] && hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess) c->prof_ms[i] += ms;
+        }
+        c->prof_steps++;
+    }
     *elbo_out = c->h_out->out[0];
     for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
     int status = 0;
@@ -692,6 +736,23 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, con
     vg_gemm_init(&g);
     vg_gemm_add(&g, T1, n2, 1, L2inv, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2);        // . L2inv
     VG_HIP(vg_gemm_launch(&g, st));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_profile(vggp_ctx* c, int enable) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_HIP(hipSetDevice(c->device));
+    if (enable && !c->ev[0])
+        for (int i = 0; i < VGGP_NSTAGE + 2; ++i) VG_HIP(hipEventCreate(&c->ev[i]));
+    c->prof = enable != 0;
+    return VGGP_OK;
+}
+
+extern "C" int vggp_profile_read(vggp_ctx* c, double ms_out[VGGP_NSTAGE], int32_t* steps_out, int reset) {
+    if (!c || !ms_out) { vg_set_error("null argument"); return VGGP_EINVAL; }
+    for (int i = 0; i < VGGP_NSTAGE; ++i) ms_out[i] = c->prof_ms[i];
+    if (steps_out) *steps_out = c->prof_steps;
+    if (reset) { for (int i = 0; i < VGGP_NSTAGE; ++i) c->prof_ms[i] = 0.0; c->prof_steps = 0; }
     return VGGP_OK;
 }
 

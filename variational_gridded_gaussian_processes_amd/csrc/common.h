@@ -110,7 +110,7 @@ struct VgEigJob {
     int m;
     int max_rounds;
 };
-hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);
 hipError_t vg_eigh_setup();
 
 // ---- m-space elementwise / reductions (mspace.hip) -----------------------------

@@ -179,13 +179,13 @@ static const int VG_EIG_LDS_MAX_M = 136;
 
 hipError_t vg_eigh_setup() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_jacobi_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_replay_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
-hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st) {
+hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid) {
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     VgEigArgs a;
     a.njobs = njobs;
@@ -208,6 +208,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st) {
     hipLaunchKernelGGL(vg_jacobi_kernel, dim3(njobs), dim3(1024), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (mid) { e = hipEventRecord(mid, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(vg_replay_kernel, dim3((maxm2 + VG_RP_COLS - 1) / VG_RP_COLS, njobs), dim3(256), lds_rp,
                        st, a);
     return hipGetLastError();

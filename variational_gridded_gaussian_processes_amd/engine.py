@@ -193,6 +193,17 @@ class Engine:
         check(self.lib.vggp_kron_solve(self._h, _ptr(L1inv), n1, _ptr(L2inv), n2, _ptr(Y), _ptr(X), _stream()))
         return X
 
+    def profile(self, enable: bool = True) -> None:
+        check(self.lib.vggp_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True):
+        """-> ({stage name: accumulated ms}, steps) measured with HIP events on the launch stream."""
+        ms = (C.c_double * _lib.NSTAGE)()
+        steps = C.c_int32()
+        check(self.lib.vggp_profile_read(self._h, ms, C.byref(steps), 1 if reset else 0))
+        names = [self.lib.vggp_stage_name(i).decode() for i in range(_lib.NSTAGE)]
+        return dict(zip(names, list(ms))), steps.value
+
     def sumsq(self, y: torch.Tensor) -> float:
         out = C.c_double()
         check(self.lib.vggp_sumsq(self._h, _ptr(y), y.numel(), C.byref(out), _stream()))
