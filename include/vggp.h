@@ -57,6 +57,13 @@ extern "C" {
 #define VGGP_BASIS_ONE    2       /* trivial factor K=[1], A=1: turns the engine into the 1-D model,
                                      univariate_structure.py:234-263, :693-717 */
 
+/* The reference keeps the B0 mesh and delta as float32 attributes (torch.linspace default
+ * dtype; Module.to(float64) does not touch them), so `(k - 1) * delta` in _Kuu_along_dim
+ * (kronecker_structure.py:731-733) is rounded to float32 before the float64 division by the
+ * lengthscale.  With this flag the B0 Kuu builder reproduces that rounding (and the literal
+ * three-exponential form) so results match the reference bit-for-bit in the inputs. */
+#define VGGP_FLAG_B0_F32_KDELTA 1
+
 typedef struct vggp_ctx vggp_ctx;
 
 /* Problem description (host struct; the small coordinate arrays are HOST pointers and
@@ -72,7 +79,7 @@ typedef struct vggp_desc {
     const double* grid1;          /* HOST: mesh [m1+1] (B0) or inducing coords [m1]   */
     const double* grid2;          /* HOST: mesh [m2+1] (B0) or inducing coords [m2]   */
     int32_t warm_start;           /* 1: reuse the previous step's eigenvectors        */
-    int32_t reserved;
+    int32_t flags;                /* VGGP_FLAG_* bit mask                             */
 } vggp_desc;
 
 /* per-step diagnostics (host struct filled by vggp_elbo_finish / vggp_elbo_step) */
@@ -138,7 +145,7 @@ int vggp_posterior(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t 
  * Replaces _Kuu_along_dim/_Kuf_along_dim (kronecker_structure.py:702-790) and the
  * pairwise kernel_d(Z), kernel(Z, x) evaluations (:318-319, :336-337). */
 int vggp_factor_build(vggp_ctx* ctx, int kind, int basis, const double* x, int64_t n,
-                      const double* grid, int64_t m, double ell,
+                      const double* grid, int64_t m, double ell, int flags,
                       double* A0, double* dA0, double* K0, double* dK0, void* stream);
 
 /* Cholesky K + jitter*I = L L^T with the psd_safe_cholesky jitter schedule (0, 1e-8,

@@ -215,7 +215,9 @@ class DenseKron:
     # -- per-dimension factors ---------------------------------------------------
     def _Kuu_d(self, d: int) -> torch.Tensor:
         th = self.theta()
-        ell, s = th[d], th[2 + d]
+        # `lengthscale[0]` in the reference is a (1,)-shaped float64 tensor (gpytorch lengthscale is (1,1)),
+        # `outputscale` is 0-dim: keep those shapes, they decide torch's type promotion against the float32 mesh
+        ell, s = th[d:d + 1], th[2 + d]
         g = self.grid_1 if d == 0 else self.grid_2
         if self.basis == "b0":
             return b0_Kuu_along_dim(g.shape[0] - 1, g[1] - g[0], ell, s)
@@ -223,7 +225,7 @@ class DenseKron:
 
     def _Kuf_d(self, d: int, x: torch.Tensor) -> torch.Tensor:
         th = self.theta()
-        ell, s = th[d], th[2 + d]
+        ell, s = th[d:d + 1], th[2 + d]
         g = self.grid_1 if d == 0 else self.grid_2
         if self.basis == "b0":
             return b0_Kuf_along_dim(g, ell, s, x)

@@ -73,6 +73,25 @@ def b0_K(m: int, delta: float, ell: float):
     return ell * ell * T, 2.0 * ell * T + ell * ell * dT
 
 
+def b0_K_f32(m: int, delta: float, ell: float):
+    """Reference-literal variant: mesh/delta are float32 there, so c*delta is rounded to float32 before the
+    float64 division (kronecker_structure.py:731-733 under torch's type promotion); three-term form."""
+    df = np.float32(delta)
+    k = np.arange(m)
+    a0 = ((k - 1).astype(np.float32) * df).astype(np.float64)
+    a1 = ((k + 1).astype(np.float32) * df).astype(np.float64)
+    a2 = (k.astype(np.float32) * df).astype(np.float64)
+    e0, e1, e2 = np.exp(-a0 / ell), np.exp(-a1 / ell), np.exp(-a2 / ell)
+    r = e0 + e1 - 2 * e2
+    dr = (e0 * a0 + e1 * a1 - 2 * e2 * a2) / ell ** 2
+    t = float(df) / ell
+    r[0] = 2 * (math.exp(-t) + t - 1)
+    dr[0] = 2 * (math.exp(-t) * t / ell - t / ell)
+    idx = np.abs(np.arange(m)[:, None] - np.arange(m)[None, :])
+    T, dT = r[idx], dr[idx]
+    return ell * ell * T, 2.0 * ell * T + ell * ell * dT
+
+
 def b0_A(mesh: np.ndarray, x: np.ndarray, ell: float):
     """Unit-outputscale Kuf_d and d/dell (kronecker_structure.py:768-790).  Cell k is
     (mesh[k], mesh[k+1]] (searchsorted right=False), x <= mesh[0] counts as below."""
@@ -96,6 +115,7 @@ class Factor:
     kind: str                   # matern12 | matern32 | matern52 | rbf
     grid: np.ndarray            # mesh (m+1 knots) for b0, inducing coords (m) for points
     x: np.ndarray               # the n_d unique observation coordinates along this dim
+    f32_kdelta: bool = False    # reproduce the reference's float32 (k*delta) rounding (float32 mesh)
 
     @property
     def m(self) -> int:
@@ -111,7 +131,7 @@ class Factor:
             return np.ones((1, 1)), np.zeros((1, 1)), o, np.zeros_like(o)
         g = np.asarray(self.grid, dtype=np.float64)
         if self.basis == "b0":
-            K, dK = b0_K(len(g) - 1, float(g[1] - g[0]), ell)
+            K, dK = (b0_K_f32 if self.f32_kdelta else b0_K)(len(g) - 1, float(g[1] - g[0]), ell)
             A, dA = b0_A(g, x, ell)
         else:
             K, dK = points_factor(self.kind, g, g, ell)

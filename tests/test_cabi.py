@@ -1,0 +1,66 @@
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/vggp.h declares, and the
+product path fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from variational_gridded_gaussian_processes_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from variational_gridded_gaussian_processes_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vggp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vggp_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layouts_match_header():
+    from variational_gridded_gaussian_processes_amd._lib import Desc, Info
+    assert C.sizeof(Desc) == 4 * 4 + 5 * 8 + 4 * 8 + 2 * 4
+    assert C.sizeof(Info) == 2 * 8 + 6 * 4
+
+
+def test_version_and_stage_names(lib):
+    assert lib.vggp_version() == 100
+    names = [lib.vggp_stage_name(i).decode() for i in range(14)]
+    assert len(set(names)) == 14 and "jacobi_eigh" in names
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu(lib):
+    from variational_gridded_gaussian_processes_amd import Engine
+    h = C.c_void_p()
+    assert lib.vggp_create(C.byref(h), 0) == -3          # VGGP_EHIP, never a silent CPU path
+    assert b"hipGetDeviceCount" in lib.vggp_last_error()
+    with pytest.raises(RuntimeError):
+        Engine()
+
+
+def test_null_context_is_an_error_not_a_crash(lib):
+    assert lib.vggp_payload_len(None) == 0
+    assert lib.vggp_qv(None, None, None, None) < 0
+    assert lib.vggp_elbo_step(None, None, 0.0, None, None, None, None, None) < 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "variational_gridded_gaussian_processes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libvggp_hip.so")
 VGGP_OK, VGGP_EINVAL, VGGP_ENOTPD, VGGP_EHIP, VGGP_ENOMEM, VGGP_ESTATE, VGGP_ENOCONV = 0, -1, -2, -3, -4, -5, -6
 KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 NSTAGE = 14
+FLAG_B0_F32_KDELTA = 1
 BASIS = {"points": 0, "b0": 1, "one": 2}
 
 
@@ -25,7 +26,7 @@ class Desc(C.Structure):
                 ("n1", C.c_int64), ("n2", C.c_int64), ("m1", C.c_int64), ("m2", C.c_int64),
                 ("n_total", C.c_int64),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("grid1", C.c_void_p), ("grid2", C.c_void_p),
-                ("warm_start", C.c_int32), ("reserved", C.c_int32)]
+                ("warm_start", C.c_int32), ("flags", C.c_int32)]
 
 
 class Info(C.Structure):
@@ -51,7 +52,7 @@ SYMBOLS = {
     "vggp_qv": (_I, [_P, _P, _P, _P]),
     "vggp_qv_cov": (_I, [_P, _P, _P]),
     "vggp_posterior": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
-    "vggp_factor_build": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _D, _P, _P, _P, _P, _P]),
+    "vggp_factor_build": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _D, _I, _P, _P, _P, _P, _P]),
     "vggp_cholesky_inverse": (_I, [_P, _P, _I64, _P, _P, C.POINTER(_D), _P]),
     "vggp_eigh": (_I, [_P, _P, _I64, _P, _P, C.POINTER(C.c_int32), _P]),
     "vggp_gemm": (_I, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P]),

@@ -306,7 +306,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     VgFactorJob fj[2];
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0};
+        fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0, c->desc.flags};
     }
     VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
     VG_MARK(1);
@@ -610,8 +610,8 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
     for (long off = 0; off < ns; off += chunk) {
         const int cn = (int)std::min<long>(chunk, ns - off);
         VgFactorJob fj[2] = {
-            VgFactorJob{xs1 + off, d1.grid, A1, nullptr, nullptr, nullptr, cn, d1.m, d1.kind, d1.basis, 0, 0.0},
-            VgFactorJob{xs2 + off, d2.grid, A2, nullptr, nullptr, nullptr, cn, d2.m, d2.kind, d2.basis, 1, 0.0}};
+            VgFactorJob{xs1 + off, d1.grid, A1, nullptr, nullptr, nullptr, cn, d1.m, d1.kind, d1.basis, 0, 0.0, c->desc.flags},
+            VgFactorJob{xs2 + off, d2.grid, A2, nullptr, nullptr, nullptr, cn, d2.m, d2.kind, d2.basis, 1, 0.0, c->desc.flags}};
         VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
         VgGemmBatch g;
         vg_gemm_init(&g);
@@ -635,7 +635,7 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
 // ---------------------------------------------------------------------------------
 // exported building blocks
 extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double* x, int64_t n, const double* grid,
-                                 int64_t m, double ell, double* A0, double* dA0, double* K0, double* dK0, void* stream) {
+                                 int64_t m, double ell, int flags, double* A0, double* dA0, double* K0, double* dK0, void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(kind >= 0 && kind <= 3 && basis >= 0 && basis <= 2, "vggp_factor_build: bad kind/basis");
     VG_REQUIRE(!(basis == VGGP_BASIS_B0 && kind != VGGP_KIND_MATERN12), "vggp_factor_build: B0 is Matern-1/2 only");
@@ -643,7 +643,7 @@ extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double*
     VG_REQUIRE(grid || basis == VGGP_BASIS_ONE, "vggp_factor_build: null grid");
     VG_REQUIRE((x || !(A0 || dA0)), "vggp_factor_build: null x");
     VG_HIP(hipSetDevice(c->device));
-    VgFactorJob j{x, grid, n > 0 ? A0 : nullptr, n > 0 ? dA0 : nullptr, K0, dK0, (int)n, (int)m, kind, basis, -1, ell};
+    VgFactorJob j{x, grid, n > 0 ? A0 : nullptr, n > 0 ? dA0 : nullptr, K0, dK0, (int)n, (int)m, kind, basis, -1, ell, flags};
     VG_HIP(vg_factor_build_launch(&j, 1, nullptr, (hipStream_t)stream));
     return VGGP_OK;
 }

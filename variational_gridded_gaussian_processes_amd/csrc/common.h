@@ -79,6 +79,7 @@ struct VgFactorJob {
     int n, m, kind, basis;
     int theta_idx;        // index of ell in the device theta vector, or -1 -> use ell_imm
     double ell_imm;
+    int flags;            // VGGP_FLAG_*
 };
 hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const double* theta_dev,
                                   hipStream_t st);

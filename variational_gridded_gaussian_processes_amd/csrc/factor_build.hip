@@ -77,6 +77,27 @@ __device__ __forceinline__ void vg_b0_K(int kd, double delta, double ell, double
     dv = 2.0 * ell * r + ell * ell * dr;
 }
 
+// Reference-literal variant (VGGP_FLAG_B0_F32_KDELTA): the products c*delta are rounded to float32 as in
+// the reference (float32 mesh attributes), then exp(-(c delta)_f32 / ell) in float64, three-term form.
+__device__ __forceinline__ void vg_b0_K_f32(int kd, double delta, double ell, double& v, double& dv) {
+    const float df = (float)delta;
+    double r, dr;
+    if (kd == 0) {
+        const double t = (double)df / ell;
+        const double e = exp(-t);
+        r = 2.0 * (e + t - 1.0);
+        dr = 2.0 * (e * t / ell - t / ell);
+    } else {
+        const double a0 = (double)((float)(kd - 1) * df), a1 = (double)((float)(kd + 1) * df),
+                     a2 = (double)((float)kd * df);
+        const double e0 = exp(-a0 / ell), e1 = exp(-a1 / ell), e2 = exp(-a2 / ell);
+        r = e0 + e1 - 2.0 * e2;
+        dr = (e0 * a0 + e1 * a1 - 2.0 * e2 * a2) / (ell * ell);
+    }
+    v = ell * ell * r;
+    dv = 2.0 * ell * r + ell * ell * dr;
+}
+
 __global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs args, const double* __restrict__ theta) {
     const int bid = blockIdx.x;
     int part = 0;
@@ -99,7 +120,8 @@ __global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs args,
     } else if (J.basis == VGGP_BASIS_B0) {
         if (kpart) {
             const int kd = k > p ? k - p : p - k;
-            vg_b0_K(kd, J.grid[1] - J.grid[0], ell, v, dv);
+            if (J.flags & VGGP_FLAG_B0_F32_KDELTA) vg_b0_K_f32(kd, J.grid[1] - J.grid[0], ell, v, dv);
+            else vg_b0_K(kd, J.grid[1] - J.grid[0], ell, v, dv);
         } else {
             vg_b0_A(J.grid[k], J.grid[k + 1], J.x[p], ell, v, dv);
         }

@@ -60,7 +60,7 @@ class Engine:
 
     # -- planning -------------------------------------------------------------------------------
     def plan(self, kind1: str, basis1: str, grid1, x1, kind2: str, basis2: str, grid2, x2,
-             n_total: Optional[int] = None, warm_start: bool = False) -> None:
+             n_total: Optional[int] = None, warm_start: bool = False, b0_f32_kdelta: bool = False) -> None:
         """grid_d: mesh (m+1 knots, basis 'b0') or inducing coordinates (m, basis 'points');
         x_d: the n_d unique (local) observation coordinates along dimension d."""
         x1, x2 = _dvec(x1), _dvec(x2)
@@ -75,6 +75,7 @@ class Engine:
         d.x1, d.x2 = x1.ctypes.data, x2.ctypes.data
         d.grid1, d.grid2 = g1.ctypes.data, g2.ctypes.data
         d.warm_start = 1 if warm_start else 0
+        d.flags = _lib.FLAG_B0_F32_KDELTA if b0_f32_kdelta else 0
         with torch.cuda.device(self.device):
             check(self.lib.vggp_plan(self._h, C.byref(d)))
         self.m1, self.m2, self.n1, self.n2 = m1, m2, len(x1), len(x2)
@@ -148,13 +149,13 @@ class Engine:
         return mean, var
 
     # -- building blocks ------------------------------------------------------------------------------
-    def factor_build(self, kind: str, basis: str, x: torch.Tensor, grid: torch.Tensor, ell: float):
+    def factor_build(self, kind: str, basis: str, x: torch.Tensor, grid: torch.Tensor, ell: float, flags: int = 0):
         """-> A0[m,n], dA0[m,n], K0[m,m], dK0[m,m] at unit outputscale."""
         n = x.shape[0]
         m = 1 if basis == "one" else (grid.shape[0] - 1 if basis == "b0" else grid.shape[0])
         o = dict(dtype=torch.float64, device=self.device)
         A, dA, K, dK = torch.empty(m, n, **o), torch.empty(m, n, **o), torch.empty(m, m, **o), torch.empty(m, m, **o)
-        check(self.lib.vggp_factor_build(self._h, KIND[kind], BASIS[basis], _ptr(x), n, _ptr(grid), m, float(ell),
+        check(self.lib.vggp_factor_build(self._h, KIND[kind], BASIS[basis], _ptr(x), n, _ptr(grid), m, float(ell), int(flags),
                                          _ptr(A), _ptr(dA), _ptr(K), _ptr(dK), _stream()))
         return A, dA, K, dK
 

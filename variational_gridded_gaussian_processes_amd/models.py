@@ -1,0 +1,438 @@
+"""Drop-in host-side mirror of the reference's model API for the Kronecker ELBO hot path.
+
+Same class names, constructor arguments, method names and attribute reads as the reference's
+notebooks use:
+
+    reference                                                    here
+    src/models/sparse/gridded_kronecker_structure.py:1255-1433   Matern12GriddedGP
+    src/models/sparse/kronecker_structure.py:671-849             Matern12B0SplineGriddedGP
+    src/models/sparse/kronecker_structure.py:287-338             Matern12SVGP (+ Matern32/52/RBF variants, new)
+    src/models/sparse/kronecker_structure.py:15-278              KroneckerStructure (base: _elbo, q_v, posterior, ...)
+    src/models/sparse/univariate_structure.py:721-825, :325-354  univariate.Matern12B0SplineGriddedGP, univariate.*SVGP
+
+`model._elbo()` returns a differentiable 0-d tensor, so the notebooks' loop
+`optimizer.zero_grad(); loss = -model._elbo(); loss.backward(); optimizer.step()` with
+`torch.optim.Adam(model.parameters(), lr)` runs unchanged -- but value and gradient come from ONE
+call into libvggp_hip.so (analytic gradient), not from autograd over dense N x N algebra.
+The gpytorch pieces the reference leans on (GaussianLikelihood, ScaleKernel, MaternKernel,
+MultivariateNormal) are mirrored here only as far as the path reads them: parameter transforms
+(softplus, noise >= 1e-4, raw init 0) and accessor names.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .engine import Engine
+
+NOISE_LOWER = 1e-4
+
+
+def _inv_softplus(y: torch.Tensor) -> torch.Tensor:
+    return y + torch.log(-torch.expm1(-y))
+
+
+# ---------------------------------------------------------------------------------------------
+# minimal mirrors of the gpytorch modules whose attributes the notebooks read
+# ---------------------------------------------------------------------------------------------
+class _BaseKernel(torch.nn.Module):
+    """MaternKernel(nu) / RBFKernel: only the lengthscale parameter lives here."""
+
+    def __init__(self, kind: str):
+        super().__init__()
+        self.kind = kind
+        self.nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5, "rbf": math.inf}[kind]
+        self.raw_lengthscale = torch.nn.Parameter(torch.zeros(1, 1))
+
+    @property
+    def lengthscale(self) -> torch.Tensor:
+        # a fresh tensor, like gpytorch's property: `kernel.lengthscale[0] = v` therefore does NOT
+        # update the raw parameter (the reference's non_informative_initialise quirk)
+        return torch.nn.functional.softplus(self.raw_lengthscale)
+
+    @lengthscale.setter
+    def lengthscale(self, value):
+        v = torch.as_tensor(value, dtype=self.raw_lengthscale.dtype).reshape(1, 1)
+        with torch.no_grad():
+            self.raw_lengthscale.copy_(_inv_softplus(v))
+
+
+class ScaleKernel(torch.nn.Module):
+    def __init__(self, base_kernel: _BaseKernel):
+        super().__init__()
+        self.base_kernel = base_kernel
+        self.raw_outputscale = torch.nn.Parameter(torch.zeros(()))
+
+    @property
+    def outputscale(self) -> torch.Tensor:
+        return torch.nn.functional.softplus(self.raw_outputscale)
+
+    @outputscale.setter
+    def outputscale(self, value):
+        v = torch.as_tensor(value, dtype=self.raw_outputscale.dtype).reshape(())
+        with torch.no_grad():
+            self.raw_outputscale.copy_(_inv_softplus(v))
+
+
+class GaussianLikelihood(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.raw_noise = torch.nn.Parameter(torch.zeros(1))
+
+    @property
+    def noise(self) -> torch.Tensor:
+        return torch.nn.functional.softplus(self.raw_noise) + NOISE_LOWER
+
+    @noise.setter
+    def noise(self, value):
+        v = torch.as_tensor(value, dtype=self.raw_noise.dtype).reshape(1)
+        with torch.no_grad():
+            self.raw_noise.copy_(_inv_softplus(v - NOISE_LOWER))
+
+
+class MultivariateNormal:
+    """What q_v()/posterior() return: `.mean`, `.variance`, `.stddev`, `.confidence_region()` and a lazily
+    materialised `.covariance_matrix` (dense, small problems only)."""
+
+    def __init__(self, mean: torch.Tensor, variance: torch.Tensor, cov_fn=None):
+        self.mean = mean
+        self._variance = variance
+        self._cov_fn = cov_fn
+        self._cov = None
+
+    @property
+    def variance(self) -> torch.Tensor:
+        return self._variance
+
+    @property
+    def stddev(self) -> torch.Tensor:
+        return self._variance.clamp_min(0).sqrt()
+
+    @property
+    def covariance_matrix(self) -> torch.Tensor:
+        if self._cov is None:
+            if self._cov_fn is None:
+                raise NotImplementedError("dense covariance is not available for this distribution; use .variance")
+            self._cov = self._cov_fn()
+        return self._cov
+
+    def confidence_region(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        s2 = 2.0 * self.stddev
+        return self.mean - s2, self.mean + s2
+
+
+class _ElboFunction(torch.autograd.Function):
+    """value + analytic gradient from one vggp_elbo_step; backward only scales the cached gradient."""
+
+    @staticmethod
+    def forward(ctx, theta: torch.Tensor, model: "KroneckerStructure"):
+        elbo, grad, info = model._engine_step([float(t) for t in theta.detach().cpu()])
+        model.last_info = info
+        ctx.save_for_backward(torch.as_tensor(grad, dtype=theta.dtype, device=theta.device))
+        return torch.as_tensor(elbo, dtype=theta.dtype, device=theta.device)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return grad_out * g, None
+
+
+def _detect_grid(X: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
+    """X (N,2) in gen_2d layout (utils/datagenerators.py:70-72: x1 fastest) -> unique (x1, x2)."""
+    Xn = X.detach().cpu().numpy().astype(np.float64)
+    if Xn.ndim != 2 or Xn.shape[1] != 2:
+        raise ValueError("X must be (N, 2)")
+    N = Xn.shape[0]
+    x2_first = Xn[0, 1]
+    n1 = int(np.argmax(Xn[:, 1] != x2_first)) if np.any(Xn[:, 1] != x2_first) else N
+    if n1 == 0 or N % n1 != 0:
+        raise ValueError("X is not a full grid in gen_2d layout (x1 fastest)")
+    n2 = N // n1
+    G = Xn.reshape(n2, n1, 2)
+    x1, x2 = G[0, :, 0].copy(), G[:, 0, 1].copy()
+    if not (np.array_equal(G[:, :, 0], np.broadcast_to(x1, (n2, n1)))
+            and np.array_equal(G[:, :, 1], np.broadcast_to(x2[:, None], (n2, n1)))):
+        raise ValueError("X is not a full grid in gen_2d layout (x1 fastest); scattered/masked "
+                         "observations are not supported by this build yet")
+    return x1, x2
+
+
+class KroneckerStructure(torch.nn.Module):
+    """kronecker_structure.py:15-278 -- the 2-D sparse-GP base class, structured engine inside."""
+
+    kind = "matern12"
+
+    def __init__(self, X: torch.Tensor, y: torch.Tensor, engine: Optional[Engine] = None, warm_start: bool = True):
+        super().__init__()
+        self.train_inputs = (X,)
+        self.train_targets = y
+        self.likelihood = GaussianLikelihood()
+        self.kernel_1 = ScaleKernel(_BaseKernel(self.kind))
+        self.kernel_2 = ScaleKernel(_BaseKernel(self.kind))
+        self._engine = engine if engine is not None else Engine()
+        self._warm = warm_start
+        self._planned = False
+        self.last_info = None
+        self._x1, self._x2 = _detect_grid(X)
+        n2, n1 = len(self._x2), len(self._x1)
+        self._Y = torch.as_tensor(y, dtype=torch.float64).reshape(n2, n1).contiguous().to(self._engine.device)
+        self._yy = self._engine.sumsq(self._Y)
+
+    # subclasses provide (basis, grid_1, grid_2)
+    def _basis(self) -> Tuple[str, np.ndarray, np.ndarray]:
+        raise NotImplementedError
+
+    def _f32_mesh(self) -> bool:
+        """True when the B0 mesh is a float32 tensor (the reference's default): reproduce its float32 k*delta."""
+        mesh = getattr(self, "mesh_1", getattr(self, "mesh", None))
+        return mesh is not None and mesh.dtype == torch.float32
+
+    def _plan(self):
+        if not self._planned:
+            basis, g1, g2 = self._basis()
+            self._engine.plan(self.kind, basis, g1, self._x1, self.kind, basis, g2, self._x2, warm_start=self._warm,
+                              b0_f32_kdelta=self._f32_mesh())
+            self._planned = True
+
+    def _theta(self) -> torch.Tensor:
+        return torch.stack([self.kernel_1.base_kernel.lengthscale.reshape(()),
+                            self.kernel_2.base_kernel.lengthscale.reshape(()),
+                            self.kernel_1.outputscale.reshape(()), self.kernel_2.outputscale.reshape(()),
+                            self.likelihood.noise.reshape(())]).to(torch.float64)
+
+    def _engine_step(self, theta):
+        self._plan()
+        return self._engine.elbo_step(self._Y, self._yy, theta)
+
+    # -- reference API ---------------------------------------------------------------------------
+    def _elbo(self) -> torch.Tensor:
+        """kronecker_structure.py:249-278 (collapsed Titsias bound at the optimal q(u))."""
+        return _ElboFunction.apply(self._theta(), self)
+
+    def _refresh(self):
+        """q_v()/posterior() read the engine state of the CURRENT hyper-parameters."""
+        with torch.no_grad():
+            _ElboFunction.apply(self._theta(), self)
+
+    def q_v(self) -> MultivariateNormal:
+        """gridded_kronecker_structure.py:1409-1433 == kronecker_structure.py:825-849.
+        mean is flat (M,) with u = i1*m2 + i2 (callers do `.mean.reshape(m, m).T`)."""
+        self._refresh()
+        mean, var = self._engine.qv()
+        return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu(),
+                                  cov_fn=lambda: self._engine.qv_cov().cpu())
+
+    def posterior(self, x_star: torch.Tensor) -> MultivariateNormal:
+        """kronecker_structure.py:199-230: mean and the diagonal of the covariance at x_star (N*, 2)."""
+        self._refresh()
+        mean, var = self._engine.posterior(torch.as_tensor(x_star, dtype=torch.float64))
+        return MultivariateNormal(mean.cpu(), var.cpu())
+
+    def posterior_predictive(self, x_star: torch.Tensor) -> MultivariateNormal:
+        """kronecker_structure.py:232-247: the likelihood adds the noise variance."""
+        p = self.posterior(x_star)
+        return MultivariateNormal(p.mean, p.variance + self.likelihood.noise.detach().to(p.variance.dtype))
+
+    def non_informative_initialise(self, lmbda: float, kappa: float) -> None:
+        """kronecker_structure.py:34-61.  As in the reference, the `lengthscale[0] = ...` assignments go
+        through the property getter and leave the raw lengthscale untouched (documented quirk)."""
+        X, y = self.train_inputs[0], self.train_targets
+        self.kernel_1.outputscale = y.var()
+        self.kernel_1.base_kernel.lengthscale[0] = (X[:, 0].std() / lmbda)
+        self.kernel_2.outputscale = y.var()
+        self.kernel_2.base_kernel.lengthscale[0] = (X[:, 1].std() / lmbda)
+        self.likelihood.noise = ((self.kernel_1.outputscale + self.kernel_2.outputscale) / 2) / (kappa ** 2)
+
+    def informative_initialise(self, prior_amplitude: float, lmbda: float) -> None:
+        """kronecker_structure.py:63-88."""
+        X, y = self.train_inputs[0], self.train_targets
+        self.kernel_1.outputscale = (torch.tensor(prior_amplitude) / 2) ** 2
+        self.kernel_1.base_kernel.lengthscale[0] = (X[:, 0].std() / lmbda)
+        self.kernel_2.outputscale = (torch.tensor(prior_amplitude) / 2) ** 2
+        self.kernel_2.base_kernel.lengthscale[0] = (X[:, 1].std() / lmbda)
+        self.likelihood.noise = y.var() - ((self.kernel_1.outputscale + self.kernel_2.outputscale) / 2)
+
+    # convenience: the notebooks' fit loop / grid prediction
+    def fit(self, n_iter: int = 100, lr: float = 0.01):
+        opt = torch.optim.Adam(self.parameters(), lr=lr)
+        history = torch.empty(n_iter)
+        for i in range(n_iter):
+            opt.zero_grad()
+            loss = -self._elbo()
+            history[i] = loss.item()
+            loss.backward()
+            opt.step()
+        return history
+
+    def predict(self) -> MultivariateNormal:
+        return self.q_v()
+
+
+class _B0Gridded(KroneckerStructure):
+    def __init__(self, X, y, nknots: int, dim1lims: Tuple[float, float], dim2lims: Tuple[float, float], **kw):
+        super().__init__(X, y, **kw)
+        self.nknots = nknots
+        self.dim1lims, self.dim2lims = dim1lims, dim2lims
+        self.mesh_1 = torch.linspace(dim1lims[0], dim1lims[1], nknots)   # default dtype, as the reference
+        self.mesh_2 = torch.linspace(dim2lims[0], dim2lims[1], nknots)
+        self.delta_1 = self.mesh_1[1] - self.mesh_1[0]
+        self.delta_2 = self.mesh_2[1] - self.mesh_2[0]
+        self.b0_mesh_1, self.b0_mesh_2 = self.mesh_1, self.mesh_2
+
+    def _basis(self):
+        return "b0", self.mesh_1.double().numpy(), self.mesh_2.double().numpy()
+
+
+class Matern12GriddedGP(_B0Gridded):
+    """gridded_kronecker_structure.py:1255-1433 (the flagship model)."""
+
+
+class Matern12B0SplineGriddedGP(_B0Gridded):
+    """kronecker_structure.py:671-849 (identical maths)."""
+
+
+class Matern12SVGP(KroneckerStructure):
+    """kronecker_structure.py:287-338: Z (m, 2) holds the per-dimension inducing coordinates; the inducing set
+    is cartesian_prod(Z[:,0], Z[:,1]) (:336), so Kuu = kron(K1(Z[:,0]), K2(Z[:,1])) (:318-321).
+    Z is kept as a buffer-like Parameter with requires_grad=False (its gradient is a 'next' item)."""
+
+    def __init__(self, X, y, Z: torch.Tensor, **kw):
+        super().__init__(X, y, **kw)
+        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=False)
+
+    def _basis(self):
+        Z = self.Z.detach().cpu().numpy()
+        return "points", Z[:, 0].copy(), Z[:, 1].copy()
+
+
+class Matern32SVGP(Matern12SVGP):
+    kind = "matern32"
+
+
+class Matern52SVGP(Matern12SVGP):
+    kind = "matern52"
+
+
+class RBFSVGP(Matern12SVGP):
+    kind = "rbf"
+
+
+# ---------------------------------------------------------------------------------------------
+# 1-D models: the same engine with a trivial second factor (VGGP_BASIS_ONE)
+# ---------------------------------------------------------------------------------------------
+class _SparseGP1D(torch.nn.Module):
+    """univariate_structure.py:15-263 (SparseGP): one factor; kernel = ScaleKernel(Matern)."""
+
+    kind = "matern12"
+
+    def __init__(self, X: torch.Tensor, y: torch.Tensor, engine: Optional[Engine] = None, warm_start: bool = True):
+        super().__init__()
+        self.train_inputs = (X,)
+        self.train_targets = y
+        self.likelihood = GaussianLikelihood()
+        self.kernel = ScaleKernel(_BaseKernel(self.kind))
+        self._engine = engine if engine is not None else Engine()
+        self._warm = warm_start
+        self._planned = False
+        self.last_info = None
+        self._x = torch.as_tensor(X, dtype=torch.float64).reshape(-1).numpy().copy()
+        self._Y = torch.as_tensor(y, dtype=torch.float64).reshape(1, -1).contiguous().to(self._engine.device)
+        self._yy = self._engine.sumsq(self._Y)
+
+    def _basis(self):
+        raise NotImplementedError
+
+    def _plan(self):
+        if not self._planned:
+            basis, g = self._basis()
+            mesh = getattr(self, "mesh", None)
+            self._engine.plan(self.kind, basis, g, self._x, "matern12", "one", None, np.zeros(1), warm_start=self._warm,
+                              b0_f32_kdelta=mesh is not None and mesh.dtype == torch.float32)
+            self._planned = True
+
+    def _theta(self):
+        one = torch.ones((), dtype=torch.float64)
+        return torch.stack([self.kernel.base_kernel.lengthscale.reshape(()).double(), one,
+                            self.kernel.outputscale.reshape(()).double(), one,
+                            self.likelihood.noise.reshape(()).double()])
+
+    def _engine_step(self, theta):
+        self._plan()
+        return self._engine.elbo_step(self._Y, self._yy, theta)
+
+    def _elbo(self):
+        """univariate_structure.py:234-263."""
+        return _ElboFunction.apply(self._theta(), self)
+
+    def _refresh(self):
+        with torch.no_grad():
+            _ElboFunction.apply(self._theta(), self)
+
+    def q_v(self) -> MultivariateNormal:
+        """univariate_structure.py:693-717."""
+        self._refresh()
+        mean, var = self._engine.qv()
+        return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu(),
+                                  cov_fn=lambda: self._engine.qv_cov().cpu())
+
+    def posterior(self, x_star) -> MultivariateNormal:
+        """univariate_structure.py:184-215 (mean and diagonal)."""
+        self._refresh()
+        mean, var = self._engine.posterior(torch.as_tensor(x_star, dtype=torch.float64).reshape(-1))
+        return MultivariateNormal(mean.cpu(), var.cpu())
+
+    def posterior_predictive(self, x_star) -> MultivariateNormal:
+        p = self.posterior(x_star)
+        return MultivariateNormal(p.mean, p.variance + self.likelihood.noise.detach().to(p.variance.dtype))
+
+    def non_informative_initialise(self, lmbda: float, kappa: float) -> None:
+        """univariate_structure.py:45-66 (same lengthscale-getter quirk)."""
+        X, y = self.train_inputs[0], self.train_targets
+        self.kernel.outputscale = y.var()
+        self.likelihood.noise = self.kernel.outputscale / (kappa ** 2)
+        self.kernel.base_kernel.lengthscale[0] = (X.std() / lmbda)
+
+    def informative_initialise(self, prior_amplitude: float, lmbda: float) -> None:
+        """univariate_structure.py:68-87."""
+        X, y = self.train_inputs[0], self.train_targets
+        self.kernel.outputscale = (torch.tensor(prior_amplitude) / 2) ** 2
+        self.likelihood.noise = y.var() - self.kernel.outputscale
+        self.kernel.base_kernel.lengthscale[0] = (X.std() / lmbda)
+
+
+class univariate:
+    """Namespace for the 1-D classes (they share names with the 2-D ones in the reference's other module)."""
+
+    class Matern12B0SplineGriddedGP(_SparseGP1D):
+        """univariate_structure.py:721-825."""
+
+        def __init__(self, X, y, nknots: int, dim1lims: Tuple[float, float], **kw):
+            super().__init__(X, y, **kw)
+            self.nknots = nknots
+            self.alim, self.blim = dim1lims
+            self.mesh = torch.linspace(self.alim, self.blim, nknots)
+            self.delta = self.mesh[1] - self.mesh[0]
+            self.n_splines = nknots - 1
+
+        def _basis(self):
+            return "b0", self.mesh.double().numpy()
+
+    class Matern12SVGP(_SparseGP1D):
+        """univariate_structure.py:273-332."""
+
+        def __init__(self, X, y, Z, **kw):
+            super().__init__(X, y, **kw)
+            self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).reshape(-1, 1).clone(),
+                                        requires_grad=False)
+
+        def _basis(self):
+            return "points", self.Z.detach().cpu().numpy().reshape(-1).copy()
+
+    class Matern32SVGP(Matern12SVGP):
+        kind = "matern32"
+
+    class Matern52SVGP(Matern12SVGP):
+        kind = "matern52"
