@@ -77,7 +77,7 @@ struct vggp_ctx {
 
 static const char* VG_STAGE_NAMES[VGGP_NSTAGE] = {
     "factor_build", "cholesky_inverse", "gemm_BV(Linv*[A|dA])", "gemm_gram+project(S=[B2;V2]Y)", "gemm_C(B1*S)",
-    "reduce_slabs", "gemm_warm_start", "jacobi_eigh", "jacobi_replay", "gemm_rotate_right", "gemm_rotate_left",
+    "reduce_slabs", "gemm_warm_start", "jacobi_eigh+replay(fused)", "(unused)", "gemm_rotate_right", "gemm_rotate_left",
     "dstage", "gemm_betaGram", "final_reduce"};
 extern "C" const char* vggp_stage_name(int i) { return (i >= 0 && i < VGGP_NSTAGE) ? VG_STAGE_NAMES[i] : ""; }
 
@@ -224,7 +224,7 @@ static int check_dim(int kind, int basis, long n, long m, const char* which) {
     VG_REQUIRE(!(basis == VGGP_BASIS_B0 && kind != VGGP_KIND_MATERN12),
                "vggp_plan: the B0 basis exists for Matern-1/2 only (%s)", which);
     VG_REQUIRE(n >= 1, "vggp_plan: %s has no observations", which);
-    VG_REQUIRE(m >= 1 && m <= 512, "vggp_plan: m=%ld for %s outside [1, 512]", m, which);
+    VG_REQUIRE(m >= 1 && m <= 256, "vggp_plan: m=%ld for %s outside [1, 256]", m, which);
     VG_REQUIRE(!(basis == VGGP_BASIS_ONE && m != 1), "vggp_plan: BASIS_ONE needs m=1 (%s)", which);
     return VGGP_OK;
 }
@@ -409,8 +409,9 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
         ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds};
     }
-    VG_HIP(vg_eigh_launch(ej, 2, st, c->prof ? c->ev[8] : nullptr));
-    if (c->prof) c->ev_set[8] = true;
+    for (int k = 0; k < 2; ++k) VG_HIP(hipMemsetAsync(c->d[k].counters, 0, 4 * sizeof(int), st));
+    VG_HIP(vg_eigh_launch(ej, 2, st));
+    VG_MARK(8);
     VG_MARK(9);
 
     // 8. rotate into the eigenbasis: first the right factors ...
@@ -674,7 +675,7 @@ extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, do
 
 extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, double* Qt, int32_t* sweeps_out, void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
-    VG_REQUIRE(G && lam && Qt && m >= 1 && m <= 512, "vggp_eigh: bad argument (1 <= m <= 512)");
+    VG_REQUIRE(G && lam && Qt && m >= 1 && m <= 256, "vggp_eigh: bad argument (1 <= m <= 256)");
     VG_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const long m2e = m + (m & 1);
@@ -736,6 +737,13 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, con
     vg_gemm_init(&g);
     vg_gemm_add(&g, T1, n2, 1, L2inv, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2);        // . L2inv
     VG_HIP(vg_gemm_launch(&g, st));
+    return VGGP_OK;
+}
+
+// diagnostic builds only (-DVG_EIG_STAMP): copy the head of the scratch buffer to the host
+extern "C" int vggp_debug_read_misc(vggp_ctx* c, void* host, int64_t bytes) {
+    if (!c || !c->misc || (size_t)bytes > c->misc_bytes) return VGGP_EINVAL;
+    VG_HIP(hipMemcpy(host, c->misc, bytes, hipMemcpyDeviceToHost));
     return VGGP_OK;
 }
 

@@ -15,11 +15,16 @@
 #include "common.h"
 
 #define VG_EIG_TOL 1e-13
+#define VG_EIG_DONE (1 << 30)   // progress word: rounds published | DONE
+#define VG_EIG_LAG 9             // rounds whose log stores may still be in flight: vmcnt(16) with >= 2 VMEM ops per storing wave per round, +1
+#define VG_UB 3            // blocks of one thread whose loads are batched
+#define VG_MAXMINE 6       // >= ceil(half*(half+1)/2 / 1024) for every m that fits LDS (half <= 92)
 
 struct VgEigArgs {
     VgEigJob job[2];
     int njobs;
     int use_lds[2];
+    int rp_cols;       // replay columns per workgroup (4 per working wave)
 };
 
 // circle-method pairing of m2 (even) players in round r: pair index k -> (p, q)
@@ -30,186 +35,430 @@ __device__ __forceinline__ void vg_pair(int m2, int r, int k, int& p, int& q) {
     q = r - k; if (q < 0) q += n1;
 }
 
+__device__ __forceinline__ int vg_tri(int i) { return (i * (i + 1)) >> 1; }
+// canonical (lower-triangular, packed) address of the symmetric element (i, j)
+__device__ __forceinline__ int vg_sym(int i, int j) { return i >= j ? vg_tri(i) + j : vg_tri(j) + i; }
+
+// per-pair record kept in LDS for the round: indices and their packed-row offsets (no integer multiplies in
+// the update loop: v_mul_lo_u32 is quarter rate), rotation (c, s)
+struct VgPairRec { int p, q, tp, tq; };
+__device__ __forceinline__ int vg_symo(int i, int ti, int j, int tj) { return i >= j ? ti + j : tj + i; }
+
+// one 2x2 block G[{pa,qa},{pb,qb}] <- Ja^T . Jb, read once / written once at its canonical addresses
+__device__ __forceinline__ void vg_block(double* W, const VgPairRec& A, double ca, double sa, const VgPairRec& B,
+                                         double cb, double sb) {
+    const int a00 = vg_symo(A.p, A.tp, B.p, B.tp), a01 = vg_symo(A.p, A.tp, B.q, B.tq);
+    const int a10 = vg_symo(A.q, A.tq, B.p, B.tp), a11 = vg_symo(A.q, A.tq, B.q, B.tq);
+    const double g00 = W[a00], g01 = W[a01], g10 = W[a10], g11 = W[a11];
+    const double h00 = cb * g00 - sb * g01, h01 = sb * g00 + cb * g01;
+    const double h10 = cb * g10 - sb * g11, h11 = sb * g10 + cb * g11;
+    W[a00] = ca * h00 - sa * h10;
+    W[a10] = sa * h00 + ca * h10;
+    W[a01] = ca * h01 - sa * h11;
+    W[a11] = sa * h01 + ca * h11;
+}
+// diagonal block of pair (p, q): three distinct elements
+__device__ __forceinline__ void vg_block_diag(double* W, const VgPairRec& A, double c, double s) {
+    const int app = A.tp + A.p, aqq = A.tq + A.q, apq = vg_symo(A.p, A.tp, A.q, A.tq);
+    const double gpp = W[app], gqq = W[aqq], gpq = W[apq];
+    const double cc = c * c, ss = s * s, cs2 = 2.0 * c * s * gpq;
+    W[app] = cc * gpp - cs2 + ss * gqq;
+    W[aqq] = ss * gpp + cs2 + cc * gqq;
+    W[apq] = (cc - ss) * gpq + c * s * (gpp - gqq);
+}
+
+// fast reciprocal / reciprocal square root: hardware seed + two Newton steps (full double accuracy for
+// normal inputs; the rotation only needs c^2 + s^2 = 1 to rounding, not a correctly rounded angle)
+__device__ __forceinline__ double vg_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double vg_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(y * 0.5, fma(-x * y, y, 1.0), y);
+    y = fma(y * 0.5, fma(-x * y, y, 1.0), y);
+    return y;
+}
+
+// Workgroup barrier of the round loop.  With G in LDS only LDS traffic has to be ordered, so the barrier
+// waits on lgkmcnt alone: a plain __syncthreads() also emits s_waitcnt vmcnt(0) and would stall every round
+// (~1.5 us) on the acknowledgement of the rotation-log global stores, which nobody in this kernel reads.
 template <bool INLDS>
-__device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, int* pq, volatile int* flag, double* red) {
+__device__ __forceinline__ void vg_round_barrier() {
+    if (INLDS) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+template <bool INLDS>
+__device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, int* act, unsigned char* isact,
+                               int* nact_s, double* red) {
     const int m = J.m;
-    const int m2 = m + (m & 1), half = m2 >> 1, ld = m2 + 1;
+    const int m2 = m + (m & 1), half = m2 >> 1;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int tx = tid & 31, ty = tid >> 5, nty = nthr >> 5;
 
-    // load (zero padded) and Frobenius norm
+    // load the lower triangle (zero padded) and the Frobenius norm
     double ss = 0.0;
     for (int idx = tid; idx < m2 * m2; idx += nthr) {
         const int i = idx / m2, j = idx - i * m2;
+        if (j > i) continue;
         const double v = (i < m && j < m) ? J.G[i * m + j] : 0.0;
-        W[i * ld + j] = v;
-        ss += v * v;
+        W[vg_tri(i) + j] = v;
+        ss += (i == j) ? v * v : 2.0 * v * v;
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
     if (!INLDS) __threadfence_block();
     __syncthreads();
     double fro = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
     const double thr = VG_EIG_TOL * sqrt(fro) / (double)m;
 
+    // round-independent block -> thread map: canonical blocks (al >= be) enumerated row by row, dealt round-robin
+    int my_al[VG_MAXMINE], my_be[VG_MAXMINE];
+    int nmine = 0;
+    {
+        const int nblk = (half * (half + 1)) >> 1;
+        int al = 0, rowstart = 0;                       // rowstart = al*(al+1)/2
+#pragma unroll
+        for (int u = 0; u < VG_MAXMINE; ++u) {
+            const int idx = tid + u * nthr;
+            my_al[u] = my_be[u] = 0;
+            if (INLDS && idx < nblk) {
+                while (rowstart + al + 1 <= idx) { rowstart += al + 1; ++al; }
+                my_al[u] = al;
+                my_be[u] = idx - rowstart;
+                nmine = u + 1;
+            }
+        }
+    }
+
+#ifdef VG_EIG_STAMP
+    unsigned long long tP = 0, tB1 = 0, tU = 0, tB2 = 0, t0s, t1s;
+#define VG_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VG_STAMP(var)
+#endif
     int nlog = 0, sweeps = 0, status = 0;
     for (int sweep = 0; sweep < VG_EIG_MAXSWEEP; ++sweep) {
         bool any = false;
         for (int r = 0; r < m2 - 1; ++r) {
             const int par = r & 1;
+#ifdef VG_EIG_STAMP
+            VG_STAMP(t0s);
+#endif
             if (tid < half) {
                 int p, q;
                 vg_pair(m2, r, tid, p, q);
-                const double gpp = W[p * ld + p], gqq = W[q * ld + q], gpq = W[p * ld + q];
+                const int tp = vg_tri(p), tq = vg_tri(q);
+                const double gpp = W[tp + p], gqq = W[tq + q], gpq = W[vg_symo(p, tp, q, tq)];
                 double c = 1.0, s = 0.0;
-                if (fabs(gpq) > thr) {
-                    const double tau = (gqq - gpp) / (2.0 * gpq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + hypot(1.0, tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
+                const bool rot = fabs(gpq) > thr;
+                if (rot) {
+                    // t = sign(tau) / (|tau| + sqrt(1 + tau^2)), tau = (gqq - gpp) / (2 gpq), written without a
+                    // division by the small pivot:  t = 2 gpq sign(d) / (|d| + sqrt(d^2 + 4 gpq^2)),  d = gqq - gpp
+                    const double d = gqq - gpp, o = 2.0 * gpq;
+                    const double ad = fabs(d), ao = fabs(o);
+                    const double big = fmax(ad, ao);
+                    const double ib = vg_rcp(big);
+                    const double dn = ad * ib, on = ao * ib;                       // scaled to avoid over/underflow
+                    const double hyp = (dn * dn + on * on) * vg_rsq(dn * dn + on * on);   // sqrt(dn^2 + on^2)
+                    double t = on * vg_rcp(dn + hyp);
+                    if ((d >= 0.0) != (o >= 0.0)) t = -t;
+                    c = vg_rsq(1.0 + t * t);
                     s = t * c;
-                    flag[par] = 1;
+                    act[atomicAdd(&nact_s[par], 1)] = tid;
                 }
+                isact[tid] = rot;
                 cs[tid] = make_double2(c, s);
-                pq[tid] = p | (q << 16);
+                pq[tid] = VgPairRec{p, q, tp, tq};
             }
-            if (tid == nthr - 1) flag[par ^ 1] = 0;
-            __syncthreads();
-            if (!flag[par]) continue;          // uniform: nothing to rotate in this round
+            if (tid == nthr - 1) nact_s[par ^ 1] = 0;
+#ifdef VG_EIG_STAMP
+            VG_STAMP(t1s); tP += t1s - t0s;
+#endif
+            vg_round_barrier<INLDS>();
+#ifdef VG_EIG_STAMP
+            VG_STAMP(t0s); tB1 += t0s - t1s;
+#endif
+            const int na = nact_s[par];
+            if (na == 0) continue;                 // uniform: nothing to rotate in this round
             if (nlog >= J.max_rounds) { status = VGGP_ENOCONV; break; }
-            if (tid < half) J.rotlog[(long)nlog * half + tid] = cs[tid];
-            if (tid == 0) J.roundlog[nlog] = r;
+            // hand-off to the replay workgroups (cdna guide G16, sc1 form): log entries are stored write-through;
+            // at the end of every logged round the storing waves wait until all but that round's own stores are
+            // done (counted vmcnt, so the wait never exposes store latency).  Hence, after the previous round's
+            // barrier, every round logged before the previous one is complete and one lane may publish that count.
+            if (tid == 0 && nlog >= VG_EIG_LAG)
+                __hip_atomic_store(&J.counters[3], nlog - VG_EIG_LAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < half) {
+                double* lp = reinterpret_cast<double*>(&J.rotlog[(long)nlog * half + tid]);
+                __hip_atomic_store(lp, cs[tid].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(lp + 1, cs[tid].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) __hip_atomic_store(&J.roundlog[nlog], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++nlog;
             any = true;
-            for (int al = ty; al < half; al += nty) {
-                const int pa = pq[al] & 0xffff, qa = pq[al] >> 16;
-                const double ca = cs[al].x, sa = cs[al].y;
-                for (int be = tx; be < half; be += 32) {
-                    const int pb = pq[be] & 0xffff, qb = pq[be] >> 16;
-                    const double cb = cs[be].x, sb = cs[be].y;
-                    const double g00 = W[pa * ld + pb], g01 = W[pa * ld + qb];
-                    const double g10 = W[qa * ld + pb], g11 = W[qa * ld + qb];
-                    // right rotation (columns pb, qb), then left rotation (rows pa, qa)
-                    const double h00 = cb * g00 - sb * g01, h01 = sb * g00 + cb * g01;
-                    const double h10 = cb * g10 - sb * g11, h11 = sb * g10 + cb * g11;
-                    W[pa * ld + pb] = ca * h00 - sa * h10;
-                    W[qa * ld + pb] = sa * h00 + ca * h10;
-                    W[pa * ld + qb] = ca * h01 - sa * h11;
-                    W[qa * ld + qb] = sa * h01 + ca * h11;
+            if (na * 2 <= half) {
+                // sparse round: only blocks in a rotating row or column change
+                for (int idx = tid; idx < na * half; idx += nthr) {
+                    const int ia = idx / half, b = idx - ia * half, a = act[ia];
+                    if (a == b) {
+                        vg_block_diag(W, pq[a], cs[a].x, cs[a].y);
+                    } else if (!isact[b] || a > b) {
+                        const int al = a > b ? a : b, be = a > b ? b : a;
+                        vg_block(W, pq[al], cs[al].x, cs[al].y, pq[be], cs[be].x, cs[be].y);
+                    }
+                }
+            } else {
+                // full round: every canonical block (al >= be).  The block -> thread map does not depend on the
+                // round, so it was hoisted (my_al/my_be); all LDS loads of a thread's blocks are issued before any
+                // math (the blocks of one round are disjoint, the compiler cannot know that).
+                if (!INLDS) {
+                    for (int al = ty; al < half; al += nty) {
+                        const VgPairRec A = pq[al];
+                        const double ca = cs[al].x, sa = cs[al].y;
+                        for (int be = tx; be <= al; be += 32) {
+                            if (be == al) vg_block_diag(W, A, ca, sa);
+                            else vg_block(W, A, ca, sa, pq[be], cs[be].x, cs[be].y);
+                        }
+                    }
+                } else
+#pragma unroll
+                for (int base = 0; base < VG_MAXMINE; base += VG_UB) {
+                    if (base >= nmine) break;
+                    VgPairRec RA[VG_UB], RB[VG_UB];
+                    double2 CA[VG_UB], CB[VG_UB];
+                    int ad[VG_UB][4];
+                    double g[VG_UB][4];
+                    bool ok[VG_UB], dg[VG_UB];
+#pragma unroll
+                    for (int u = 0; u < VG_UB; ++u) {
+                        ok[u] = base + u < nmine;
+                        const int al = ok[u] ? my_al[base + u] : 0, be = ok[u] ? my_be[base + u] : 0;
+                        dg[u] = al == be;
+                        RA[u] = pq[al]; CA[u] = cs[al];
+                        RB[u] = pq[be]; CB[u] = cs[be];
+                    }
+#pragma unroll
+                    for (int u = 0; u < VG_UB; ++u) {
+                        ad[u][0] = vg_symo(RA[u].p, RA[u].tp, RB[u].p, RB[u].tp);
+                        ad[u][1] = vg_symo(RA[u].p, RA[u].tp, RB[u].q, RB[u].tq);
+                        ad[u][2] = vg_symo(RA[u].q, RA[u].tq, RB[u].p, RB[u].tp);
+                        ad[u][3] = vg_symo(RA[u].q, RA[u].tq, RB[u].q, RB[u].tq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[u][e] = W[ad[u][e]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < VG_UB; ++u) {
+                        if (!ok[u]) continue;
+                        const double ca = CA[u].x, sa = CA[u].y, cb = CB[u].x, sb = CB[u].y;
+                        if (dg[u]) {
+                            // diagonal block: g[0]=gpp, g[1]=g[2]=gpq, g[3]=gqq
+                            const double gpp = g[u][0], gpq = g[u][1], gqq = g[u][3];
+                            const double cc = ca * ca, ss = sa * sa, cs2 = 2.0 * ca * sa * gpq;
+                            W[ad[u][0]] = cc * gpp - cs2 + ss * gqq;
+                            W[ad[u][3]] = ss * gpp + cs2 + cc * gqq;
+                            W[ad[u][1]] = (cc - ss) * gpq + ca * sa * (gpp - gqq);
+                        } else {
+                            const double h00 = cb * g[u][0] - sb * g[u][1], h01 = sb * g[u][0] + cb * g[u][1];
+                            const double h10 = cb * g[u][2] - sb * g[u][3], h11 = sb * g[u][2] + cb * g[u][3];
+                            W[ad[u][0]] = ca * h00 - sa * h10;
+                            W[ad[u][2]] = sa * h00 + ca * h10;
+                            W[ad[u][1]] = ca * h01 - sa * h11;
+                            W[ad[u][3]] = sa * h01 + ca * h11;
+                        }
+                    }
                 }
             }
-            if (!INLDS) __threadfence_block();
-            __syncthreads();
+#ifdef VG_EIG_STAMP
+            VG_STAMP(t1s); tU += t1s - t0s;
+#endif
+            // <= 4 VMEM ops per wave per round; write-through (sc1) stores take a few microseconds to be acknowledged,
+            // so VG_EIG_LAG rounds are left in flight: everything older is done when this returns
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            vg_round_barrier<INLDS>();
+#ifdef VG_EIG_STAMP
+            VG_STAMP(t0s); tB2 += t0s - t1s;
+#endif
         }
         ++sweeps;
         if (status || !any) break;
         if (sweep == VG_EIG_MAXSWEEP - 1) status = VGGP_ENOCONV;
     }
     __syncthreads();
-    for (int i = tid; i < m; i += nthr) J.lam[i] = W[i * ld + i];
+    for (int i = tid; i < m; i += nthr) J.lam[i] = W[vg_tri(i) + i];
     if (tid == 0) {
         J.counters[0] = nlog;
         J.counters[1] = sweeps;
         J.counters[2] = status;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef VG_EIG_STAMP
+    if ((tid & 63) == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(J.gwork) + (tid >> 6) * 4;
+        dbg[0] = tP; dbg[1] = tB1; dbg[2] = tU; dbg[3] = tB2;
+    }
+#endif
 }
 
-__global__ __launch_bounds__(1024) void vg_jacobi_kernel(const VgEigArgs a) {
-    extern __shared__ double vg_eig_dyn[];
-    __shared__ double2 cs[512];
-    __shared__ int pq[512];
-    __shared__ int flag[2];
-    __shared__ double red[16];
-    const VgEigJob& J = a.job[blockIdx.x];
-    if (a.use_lds[blockIdx.x]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, flag, red);
-    else vg_jacobi_body<false>(J, J.gwork, cs, pq, flag, red);
-}
-
-// ---- rotation-log replay on column blocks of Q^T ---------------------------------
-#define VG_RP_COLS 16          // columns per workgroup (4 per wave)
-#define VG_RP_LD 17
+// ---- replay role: a block of VG_RP_COLS columns of Q^T per workgroup, fed by the producer's log ----------
 #define VG_RP_CHUNK_BYTES 16384
 
-__global__ __launch_bounds__(256) void vg_replay_kernel(const VgEigArgs a) {
-    extern __shared__ double vg_rp_dyn[];
-    const VgEigJob& J = a.job[blockIdx.y];
+__device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, double* dyn, int* s_sync) {
     const int m = J.m, m2 = m + (m & 1), half = m2 >> 1;
-    const int j0 = blockIdx.x * VG_RP_COLS;
+    const int VG_RP_LD = VG_RP_COLS + 1, csh = VG_RP_COLS == 64 ? 6 : (VG_RP_COLS == 32 ? 5 : 4);
+    const int j0 = cblock * VG_RP_COLS;
     if (j0 >= m2) return;
-    double* T = vg_rp_dyn;                                   // [m2][17]
+    double* T = dyn;                                          // [m2][65]
     double2* chunk = reinterpret_cast<double2*>(T + (long)m2 * VG_RP_LD);
+    int* rchunk = reinterpret_cast<int*>(chunk + VG_RP_CHUNK_BYTES / sizeof(double2));
     int rounds_per_chunk = VG_RP_CHUNK_BYTES / (half * (int)sizeof(double2));
     if (rounds_per_chunk < 1) rounds_per_chunk = 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rounds_per_chunk > 1024) rounds_per_chunk = 1024;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int idx = tid; idx < m2 * VG_RP_COLS; idx += 256) {
-        const int i = idx >> 4, jj = idx & 15, j = j0 + jj;
+    for (int idx = tid; idx < m2 * VG_RP_COLS; idx += nthr) {
+        const int i = idx >> csh, jj = idx & (VG_RP_COLS - 1), j = j0 + jj;
         double v = (i == j) ? 1.0 : 0.0;
         if (J.Qt0 && i < m && j < m) v = J.Qt0[i * m + j];
         T[i * VG_RP_LD + jj] = v;
     }
-    const int nlog = J.counters[0];
     const int jj = wave * 4 + (lane & 3);                   // this lane's column inside the block
-    for (int k0 = 0; k0 < nlog; k0 += rounds_per_chunk) {
-        const int nr = min(rounds_per_chunk, nlog - k0);
-        __syncthreads();                                     // previous chunk fully consumed / T initialised
-        for (int idx = tid; idx < nr * half; idx += 256) chunk[idx] = J.rotlog[(long)k0 * half + idx];
-        __syncthreads();
-        for (int kk = 0; kk < nr; ++kk) {
-            const int r = J.roundlog[k0 + kk];
-            for (int al = lane >> 2; al < half; al += 16) {
-                int p, q;
-                vg_pair(m2, r, al, p, q);
-                const double2 c = chunk[kk * half + al];
-                const double tp = T[p * VG_RP_LD + jj], tq = T[q * VG_RP_LD + jj];
-                T[p * VG_RP_LD + jj] = c.x * tp - c.y * tq;
-                T[q * VG_RP_LD + jj] = c.y * tp + c.x * tq;
+    const bool colwave = wave * 4 < VG_RP_COLS;              // waves beyond the tile only help with the loads
+    int consumed = 0;
+    for (;;) {
+        // one lane polls the producer's progress word (relaxed, agent scope), then the workgroup rendezvous
+        if (tid == 0) {
+            int pw, spins = 0;
+            for (;;) {
+                pw = __hip_atomic_load(&J.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int avail = (pw & (VG_EIG_DONE - 1)) - consumed;
+                if ((pw & VG_EIG_DONE) || avail >= rounds_per_chunk || avail >= 32) break;
+                if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; break; }   // bounded spin: never hang the GPU
+                __builtin_amdgcn_s_sleep(8);
             }
+            s_sync[0] = pw;
         }
+        __syncthreads();
+        const int pw = s_sync[0];
+        const bool done = (pw & VG_EIG_DONE) != 0;
+        if (pw & 0x20000000) break;                          // producer never showed up (timeout)
+        const int published = pw & 0x1fffffff;
+        const int nr = min(rounds_per_chunk, published - consumed);
+        if (nr > 0) {
+            for (int idx = tid; idx < nr * half; idx += nthr) {
+                const double* lp = reinterpret_cast<const double*>(&J.rotlog[(long)consumed * half + idx]);
+                const double cx = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double cy = __hip_atomic_load(lp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                chunk[idx] = make_double2(cx, cy);
+            }
+            for (int idx = tid; idx < nr; idx += nthr)
+                rchunk[idx] = __hip_atomic_load(&J.roundlog[consumed + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            for (int kk = 0; colwave && kk < nr; ++kk) {
+                const int r = rchunk[kk];
+                // the pairs of one round touch disjoint rows: issue all loads of a batch of 4 before the math
+                for (int al0 = lane >> 2; al0 < half; al0 += 64) {
+                    int ap[4], aq[4];
+                    double2 c[4];
+                    double tp[4], tq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int al = al0 + 16 * u;
+                        c[u] = make_double2(1.0, 0.0);
+                        ap[u] = aq[u] = jj;
+                        if (al < half) {
+                            c[u] = chunk[kk * half + al];
+                            int p, q;
+                            vg_pair(m2, r, al, p, q);
+                            ap[u] = p * VG_RP_LD + jj;
+                            aq[u] = q * VG_RP_LD + jj;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { tp[u] = T[ap[u]]; tq[u] = T[aq[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (c[u].y != 0.0) {                 // identity rotations (pair below threshold) are skipped
+                            T[ap[u]] = c[u].x * tp[u] - c[u].y * tq[u];
+                            T[aq[u]] = c[u].y * tp[u] + c[u].x * tq[u];
+                        }
+                    }
+                }
+            }
+            consumed += nr;
+        }
+        __syncthreads();                                     // s_sync / chunk reuse
+        if (done && consumed >= published) break;
     }
     __syncthreads();
-    for (int idx = tid; idx < m * VG_RP_COLS; idx += 256) {
-        const int i = idx >> 4, j = j0 + (idx & 15);
-        if (j < m) J.Qt[i * m + j] = T[i * VG_RP_LD + (idx & 15)];
+    for (int idx = tid; idx < m * VG_RP_COLS; idx += nthr) {
+        const int i = idx >> csh, j = j0 + (idx & (VG_RP_COLS - 1));
+        if (j < m) J.Qt[i * m + j] = T[i * VG_RP_LD + (idx & (VG_RP_COLS - 1))];
     }
 }
 
-static const int VG_EIG_LDS_MAX_M = 136;
+// One launch, two roles: blockIdx.x == 0 is the Jacobi producer of matrix blockIdx.y, blockIdx.x >= 1 replay its
+// rotation log on column block blockIdx.x-1 of Q^T while the producer is still running (the replay is ~3x faster
+// per round, so it finishes a few microseconds after the producer).  At most 2*(1+8) workgroups: always co-resident.
+__global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
+    extern __shared__ double vg_eig_dyn[];
+    __shared__ double2 cs[512];
+    __shared__ VgPairRec pq[512];
+    __shared__ int act[512];
+    __shared__ unsigned char isact[512];
+    __shared__ int nact_s[2];
+    __shared__ double red[16];
+    const VgEigJob& J = a.job[blockIdx.y];
+    if (blockIdx.x == 0) {
+        if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red);
+        else vg_jacobi_body<false>(J, J.gwork, cs, pq, act, isact, nact_s, red);
+    } else {
+        vg_replay_body(J, blockIdx.x - 1, a.rp_cols, vg_eig_dyn, nact_s);
+    }
+}
+
+static const int VG_EIG_LDS_MAX_M = 184;      // packed lower triangle: 184*185/2*8 B = 136 KB (+ ~19 KB static)
 
 hipError_t vg_eigh_setup() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_jacobi_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_replay_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
 }
 
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid) {
+    (void)mid;
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     VgEigArgs a;
     a.njobs = njobs;
-    size_t lds = 0, lds_rp = 0;
+    size_t lds = 0;
     int maxm2 = 0;
+    for (int j = 0; j < njobs; ++j) maxm2 = jobs[j].m + 1 > maxm2 ? jobs[j].m + 1 : maxm2;
+    // 16 columns (4 working waves) per replay workgroup: with more, the consumer's own CU becomes the bottleneck
+    const int VG_RP_COLS = 16, VG_RP_LD = VG_RP_COLS + 1;
+    a.rp_cols = VG_RP_COLS;
+    maxm2 = 0;
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         const int m = jobs[j].m;
-        if (m < 1 || m > 1024) return hipErrorInvalidValue;
+        if (m < 1 || m > 256) return hipErrorInvalidValue;
         const int m2 = m + (m & 1);
         a.use_lds[j] = m <= VG_EIG_LDS_MAX_M;
-        if (a.use_lds[j]) {
-            size_t need = (size_t)m2 * (m2 + 1) * sizeof(double);
-            if (need > lds) lds = need;
-        }
-        size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 8192;
-        if (rp > lds_rp) lds_rp = rp;
+        size_t need = a.use_lds[j] ? (size_t)m2 * (m2 + 1) / 2 * sizeof(double) : 0;
+        const size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
+        if (rp > need) need = rp;
+        if (need > lds) lds = need;
         if (m2 > maxm2) maxm2 = m2;
     }
-    hipLaunchKernelGGL(vg_jacobi_kernel, dim3(njobs), dim3(1024), lds, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (mid) { e = hipEventRecord(mid, st); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(vg_replay_kernel, dim3((maxm2 + VG_RP_COLS - 1) / VG_RP_COLS, njobs), dim3(256), lds_rp,
-                       st, a);
+    if (lds > 140 * 1024) return hipErrorInvalidValue;
+    const int ncb = (maxm2 + VG_RP_COLS - 1) / VG_RP_COLS;
+    hipLaunchKernelGGL(vg_eigh_kernel, dim3(1 + ncb, njobs), dim3(1024), lds, st, a);
     return hipGetLastError();
 }
