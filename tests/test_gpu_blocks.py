@@ -108,3 +108,18 @@ def test_kron_solve(engine):
 def test_sumsq(engine):
     y = torch.randn(100003, dtype=torch.float64, device=DEV)
     assert abs(engine.sumsq(y) - float((y * y).sum())) < 1e-9 * float((y * y).sum())
+
+
+@pytest.mark.parametrize("m", [128, 130, 150])
+def test_eigh_bitwise_repeatable(engine, m):
+    """Fixed reduction/rotation order: repeated solves are bit-identical (also exercises odd pair counts,
+    two angle-phase waves, sparse rounds and the concurrent log hand-off to the replay workgroups)."""
+    f = Kr.Factor("points", "matern12", np.linspace(0, 1, m), np.linspace(0, 1, 4 * m + 3))
+    d = Kr.dim_prepare(f, 0.2, 1.0)
+    G = torch.tensor(d.B @ d.B.T, device=DEV)
+    lam0, Qt0, _ = engine.eigh(G)
+    for _ in range(4):
+        lam, Qt, _ = engine.eigh(G)
+        assert torch.equal(lam, lam0) and torch.equal(Qt, Qt0)
+    Gn, Q = G.cpu().numpy(), Qt0.cpu().numpy()
+    assert np.linalg.norm(Q @ Gn @ Q.T - np.diag(lam0.cpu().numpy())) < 2e-13 * np.linalg.norm(Gn)

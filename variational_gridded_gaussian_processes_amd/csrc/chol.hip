@@ -1,18 +1,22 @@
-// Cholesky factorisation with the psd_safe_cholesky jitter schedule and the explicit inverse of
-// the factor, one workgroup (1024 threads) per matrix, matrix resident in LDS (m <= 136 in fp64;
-// larger factors work out of an L2-resident global scratch with the same code).
+// Cholesky factorisation with the psd_safe_cholesky jitter schedule and the explicit inverse of the factor.
 //
 // Replaces the Cholesky hidden inside lazify(Kuu).inv_matmul(Kuf) and MultivariateNormal.log_prob
-// (kronecker_structure.py:269, :273) -- applied to the m_d x m_d per-dimension factors instead of
-// the M x M / N x N dense matrices.  The explicit L^{-1} turns every later triangular solve into
-// an MFMA GEMM (numerically validated against substitution in DESIGN.md: <= 1e-8 relative on the
-// ill-conditioned RBF factors with the 1e-8 jitter).
+// (kronecker_structure.py:269, :273) -- applied to the m_d x m_d per-dimension factors instead of the M x M /
+// N x N dense matrices.  The explicit L^{-1} turns every later triangular solve into an MFMA GEMM (validated
+// against substitution in DESIGN.md: <= 1e-8 relative on the ill-conditioned RBF factors with the 1e-8 jitter).
 //
-// Phase 1  right-looking Cholesky on the lower triangle, one barrier per column; the column
-//          scaling is deferred (L[i][k] = W[i][k] / sqrt(W[k][k]) once at the end).
-// Phase 2  L^{-1} column by column: 8 lanes per column split the dot product of the forward
-//          substitution and combine with 3 xor-shuffles; the solution is kept in the (unused)
-//          upper triangle of the same LDS tile.
+// Fast path (m <= 184), one workgroup of 1024 threads per (matrix, jitter level):
+//   * the four jitter levels (0, 1e-8, 1e-7, 1e-6) are factored CONCURRENTLY by four workgroups; the lowest
+//     level that succeeds wins (identical to trying them in order) and only the winner computes the inverse and
+//     writes the outputs.  A near-singular RBF factor therefore costs one factorisation latency, not two.
+//   * register-resident right-looking Cholesky: thread (ty, tx) owns the trailing-matrix elements
+//     (ty + 32a, tx + 32b) for the whole factorisation; only the pivot column travels through LDS (packed lower
+//     triangle), so a column step is one barrier + 2*MT LDS reads + MT^2 FMAs instead of a serial chain of LDS
+//     read-modify-writes.
+//   * L^{-1} by forward elimination on the identity, same ownership: per step the finished row k is broadcast
+//     through a double-buffered LDS row, every thread updates its own elements in registers.
+// Generic path (m > 184): the matrix lives in an L2-resident global scratch, one workgroup tries the levels in
+// order (slow; only used by the building-block API for large matrices).
 #include "common.h"
 
 __constant__ double VG_JITTERS[4] = {0.0, 1e-8, 1e-7, 1e-6};
@@ -20,15 +24,160 @@ __constant__ double VG_JITTERS[4] = {0.0, 1e-8, 1e-7, 1e-6};
 struct VgCholArgs {
     VgCholJob job[4];
     int njobs;
-    int use_lds[4];
+    int fast[4];
 };
 
-template <bool INLDS>
-__device__ void vg_chol_body(const VgCholJob& J, double* W, double* sd, int* s_flag) {
+__device__ __forceinline__ int vg_ctri(int i) { return (i * (i + 1)) >> 1; }
+
+// ---- fast path -----------------------------------------------------------------------------------------------
+template <int MT>
+__device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd, double* rowbuf, int* s_i) {
+    const int m = J.m;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const double jit = VG_JITTERS[lvl];
+    int* flags = reinterpret_cast<int*>(J.scratch);          // [4] per matrix, zeroed by the launcher
+
+    double a[MT][MT];
+    int trow[MT], tcol[MT];                                    // packed-row offsets of my rows / of my columns' rows
+#pragma unroll
+    for (int ia = 0; ia < MT; ++ia) {
+        trow[ia] = vg_ctri(ty + 32 * ia);
+        tcol[ia] = vg_ctri(tx + 32 * ia);
+#pragma unroll
+        for (int ib = 0; ib < MT; ++ib) {
+            const int i = ty + 32 * ia, j = tx + 32 * ib;
+            a[ia][ib] = (i < m && j <= i) ? J.K[(long)i * m + j] + (i == j ? jit : 0.0) : 0.0;
+        }
+    }
+
+    bool ok = true;
+    int pivoff = 0;
+    for (int k = 0; k < m; ++k) {
+        const int kb = k >> 5, kx = k & 31;
+        if (tx == kx) {                                       // owners of column k publish it (rows >= k)
+#pragma unroll
+            for (int ib = 0; ib < MT; ++ib)
+                if (ib == kb) {
+#pragma unroll
+                    for (int ia = 0; ia < MT; ++ia) {
+                        const int i = ty + 32 * ia;
+                        if (i >= k && i < m) W[trow[ia] + k] = a[ia][ib];
+                    }
+                }
+        }
+        __syncthreads();
+        // all LDS reads of the step are issued together (pivot, my rows' and my columns' entries of column k)
+        const double piv = W[pivoff];
+        pivoff += k + 2;                                      // tri(k+1) + (k+1)
+        double li[MT], lj[MT];
+#pragma unroll
+        for (int ia = 0; ia < MT; ++ia) {
+            const int i = ty + 32 * ia, j = tx + 32 * ia;
+            li[ia] = (i > k && i < m) ? W[trow[ia] + k] : 0.0;
+            lj[ia] = (j > k && j < m) ? W[tcol[ia] + k] : 0.0;
+        }
+        if (!(piv > 0.0) || !(piv < 1.0e300)) { ok = false; break; }      // uniform
+        double rp = __builtin_amdgcn_rcp(piv);                // 1/piv: hardware seed + 2 Newton steps
+        rp = fma(rp, fma(-piv, rp, 1.0), rp);
+        rp = fma(rp, fma(-piv, rp, 1.0), rp);
+#pragma unroll
+        for (int ia = 0; ia < MT; ++ia) {
+            const double lr = li[ia] * rp;
+#pragma unroll
+            for (int ib = 0; ib < MT; ++ib) a[ia][ib] -= lr * lj[ib];
+        }
+    }
+
+    // ---- level selection: the lowest successful level wins (relaxed agent-scope flags, no payload) ----------
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(&flags[lvl], ok ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int win = ok ? 1 : 0, spins = 0;
+        bool all_failed = !ok;
+        for (int l = 0; l < lvl; ++l) {
+            int f;
+            while ((f = __hip_atomic_load(&flags[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                if (++spins > (1 << 22)) { f = 2; break; }   // bounded: a missing sibling counts as failed
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (f == 1) { win = 0; all_failed = false; }
+        }
+        s_i[0] = win;
+        s_i[1] = (lvl == 3 && all_failed) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool winner = s_i[0] != 0, report_fail = s_i[1] != 0;
+    if (report_fail) {
+        if (tid == 0) { *J.status = VGGP_ENOTPD; if (J.jitter_out) *J.jitter_out = -1.0; }
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int idx = tid; idx < m * m; idx += blockDim.x) { J.L[idx] = qnan; J.Linv[idx] = qnan; }
+    }
+    if (!winner) return;
+    if (tid == 0 && J.jitter_out) *J.jitter_out = jit;
+
+    // ---- scale: L[i][k] = W[i][k] / sqrt(W[k][k]) ---------------------------------------------------------------
+    for (int k = tid; k < m; k += blockDim.x) rsd[k] = 1.0 / sqrt(W[vg_ctri(k) + k]);      // 1 / L[k][k]
+    __syncthreads();
+    for (int i = ty; i < m; i += 32)
+        for (int k = tx; k <= i; k += 32) {
+            const double v = W[vg_ctri(i) + k] * rsd[k];
+            W[vg_ctri(i) + k] = v;
+            J.L[(long)i * m + k] = v;
+        }
+    for (int i = ty; i < m; i += 32)
+        for (int k = tx; k < m; k += 32)
+            if (k > i) J.L[(long)i * m + k] = 0.0;
+    __syncthreads();
+
+    // ---- inverse by forward elimination on the identity (registers hold X, lower triangular) --------------------
+#pragma unroll
+    for (int ia = 0; ia < MT; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < MT; ++ib) a[ia][ib] = (ty + 32 * ia == tx + 32 * ib) ? 1.0 : 0.0;
+    for (int k = 0; k < m; ++k) {
+        const int ka = k >> 5, ky = k & 31;
+        double* rb = rowbuf + (k & 1) * 192;
+        if (ty == ky) {                                       // owners of row k: finish it and broadcast
+            const double rk = rsd[k];                         // 1 / L[k][k]
+#pragma unroll
+            for (int ia = 0; ia < MT; ++ia)
+                if (ia == ka) {
+#pragma unroll
+                    for (int ib = 0; ib < MT; ++ib) {
+                        const int j = tx + 32 * ib;
+                        a[ia][ib] *= rk;
+                        if (j <= k) rb[j] = a[ia][ib];
+                    }
+                }
+        }
+        __syncthreads();
+        double li[MT], xr[MT];
+#pragma unroll
+        for (int ia = 0; ia < MT; ++ia) {
+            const int i = ty + 32 * ia, j = tx + 32 * ia;
+            li[ia] = (i > k && i < m) ? W[trow[ia] + k] : 0.0;
+            xr[ia] = (j <= k) ? rb[j] : 0.0;
+        }
+#pragma unroll
+        for (int ia = 0; ia < MT; ++ia)
+#pragma unroll
+            for (int ib = 0; ib < MT; ++ib) a[ia][ib] -= li[ia] * xr[ib];
+    }
+#pragma unroll
+    for (int ia = 0; ia < MT; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < MT; ++ib) {
+            const int i = ty + 32 * ia, j = tx + 32 * ib;
+            if (i < m && j < m) J.Linv[(long)i * m + j] = (j <= i) ? a[ia][ib] : 0.0;
+        }
+}
+
+// ---- generic path (any m <= 1024, matrix in global scratch, levels in order) --------------------------------------
+__device__ void vg_chol_generic(const VgCholJob& J, double* sd) {
     const int m = J.m, ld = m + 1;
+    double* W = J.scratch;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int tx = tid & 31, ty = tid >> 5;     // 32 x 32 thread tile for the trailing update
-    const int nty = nthr >> 5;
+    const int tx = tid & 31, ty = tid >> 5, nty = nthr >> 5;
     int used = -1;
     for (int attempt = 0; attempt < 4; ++attempt) {
         const double jit = VG_JITTERS[attempt];
@@ -36,18 +185,18 @@ __device__ void vg_chol_body(const VgCholJob& J, double* W, double* sd, int* s_f
             const int i = idx / m, j = idx - i * m;
             W[i * ld + j] = J.K[idx] + (i == j ? jit : 0.0);
         }
-        if (!INLDS) __threadfence_block();
+        __threadfence_block();
         __syncthreads();
         bool ok = true;
         for (int k = 0; k < m; ++k) {
             const double piv = W[k * ld + k];
-            if (!(piv > 0.0) || !(piv < 1.0e300)) { ok = false; break; }   // uniform: same value everywhere
+            if (!(piv > 0.0) || !(piv < 1.0e300)) { ok = false; break; }
             const double rp = 1.0 / piv;
             for (int i = k + 1 + ty; i < m; i += nty) {
                 const double lik = W[i * ld + k] * rp;
                 for (int j = k + 1 + tx; j <= i; j += 32) W[i * ld + j] -= lik * W[j * ld + k];
             }
-            if (!INLDS) __threadfence_block();
+            __threadfence_block();
             __syncthreads();
         }
         if (ok) { used = attempt; break; }
@@ -60,8 +209,6 @@ __device__ void vg_chol_body(const VgCholJob& J, double* W, double* sd, int* s_f
         return;
     }
     if (tid == 0 && J.jitter_out) *J.jitter_out = VG_JITTERS[used];
-
-    // deferred column scaling
     for (int k = tid; k < m; k += nthr) sd[k] = sqrt(W[k * ld + k]);
     __syncthreads();
     for (int idx = tid; idx < m * m; idx += nthr) {
@@ -69,16 +216,13 @@ __device__ void vg_chol_body(const VgCholJob& J, double* W, double* sd, int* s_f
         if (i > k) W[i * ld + k] /= sd[k];
         else if (i == k) W[i * ld + k] = sd[k];
     }
-    if (!INLDS) __threadfence_block();
+    __threadfence_block();
     __syncthreads();
-
-    // write L (before the upper triangle is reused for the inverse)
     for (int idx = tid; idx < m * m; idx += nthr) {
         const int i = idx / m, j = idx - i * m;
         J.L[idx] = (j <= i) ? W[i * ld + j] : 0.0;
     }
-
-    // explicit inverse: column j of L^{-1} stored at W[j][i], i > j
+    // column j of L^{-1} kept in the (unused) upper triangle: 8 lanes split each forward-substitution dot product
     const int sub = tid & 7, grp = tid >> 3, ngrp = nthr >> 3;
     for (int jb = 0; jb < m; jb += ngrp) {
         const int j = jb + grp;
@@ -95,11 +239,11 @@ __device__ void vg_chol_body(const VgCholJob& J, double* W, double* sd, int* s_f
                 part += __shfl_xor(part, 4);
                 const double xi = -part / W[i * ld + i];
                 if (sub == 0) W[j * ld + i] = xi;
-                if (!INLDS) __threadfence_block();
+                __threadfence_block();
             }
         }
     }
-    if (!INLDS) __threadfence_block();
+    __threadfence_block();
     __syncthreads();
     for (int idx = tid; idx < m * m; idx += nthr) {
         const int i = idx / m, j = idx - i * m;
@@ -113,17 +257,23 @@ __device__ void vg_chol_body(const VgCholJob& J, double* W, double* sd, int* s_f
 __global__ __launch_bounds__(1024) void vg_chol_kernel(const VgCholArgs a) {
     extern __shared__ double vg_chol_dyn[];
     __shared__ double sd[1024];
-    __shared__ int s_flag;
-    const VgCholJob& J = a.job[blockIdx.x];
-    if (a.use_lds[blockIdx.x]) vg_chol_body<true>(J, vg_chol_dyn, sd, &s_flag);
-    else vg_chol_body<false>(J, J.scratch, sd, &s_flag);
+    __shared__ double rowbuf[2 * 192];
+    __shared__ int s_i[2];
+    const VgCholJob& J = a.job[blockIdx.y];
+    const int lvl = blockIdx.x;
+    if (a.fast[blockIdx.y]) {
+        if (J.m <= 128) vg_chol_fast<4>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
+        else vg_chol_fast<6>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
+    } else if (lvl == 0) {
+        vg_chol_generic(J, sd);
+    }
 }
 
-static const int VG_CHOL_LDS_MAX_M = 136;
+static const int VG_CHOL_FAST_MAX_M = 184;      // packed triangle in LDS: 184*185/2*8 B = 136 KB
 
 hipError_t vg_chol_setup() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_chol_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
 }
 
 hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
@@ -133,13 +283,15 @@ hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
     size_t lds = 0;
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
-        if (jobs[j].m > 1024) return hipErrorInvalidValue;
-        a.use_lds[j] = jobs[j].m <= VG_CHOL_LDS_MAX_M;
-        if (a.use_lds[j]) {
-            size_t need = (size_t)jobs[j].m * (jobs[j].m + 1) * sizeof(double);
+        if (jobs[j].m > 1024 || jobs[j].m < 1) return hipErrorInvalidValue;
+        a.fast[j] = jobs[j].m <= VG_CHOL_FAST_MAX_M;
+        if (a.fast[j]) {
+            const size_t need = (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double);
             if (need > lds) lds = need;
+            hipError_t e = hipMemsetAsync(jobs[j].scratch, 0, 64, st);      // level flags
+            if (e != hipSuccess) return e;
         }
     }
-    hipLaunchKernelGGL(vg_chol_kernel, dim3(njobs), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL(vg_chol_kernel, dim3(4, njobs), dim3(1024), lds, st, a);
     return hipGetLastError();
 }

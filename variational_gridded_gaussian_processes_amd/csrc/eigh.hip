@@ -17,6 +17,9 @@
 #define VG_EIG_TOL 1e-13
 #define VG_EIG_DONE (1 << 30)   // progress word: rounds published | DONE
 #define VG_EIG_LAG 9             // rounds whose log stores may still be in flight: vmcnt(16) with >= 2 VMEM ops per storing wave per round, +1
+#ifndef VG_SPARSE_OK
+#define VG_SPARSE_OK 1
+#endif
 #define VG_UB 3            // blocks of one thread whose loads are batched
 #define VG_MAXMINE 6       // >= ceil(half*(half+1)/2 / 1024) for every m that fits LDS (half <= 92)
 
@@ -174,7 +177,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
                     if ((d >= 0.0) != (o >= 0.0)) t = -t;
                     c = vg_rsq(1.0 + t * t);
                     s = t * c;
-                    act[atomicAdd(&nact_s[par], 1)] = tid;
+                    atomicAdd(&nact_s[par], 1);
                 }
                 isact[tid] = rot;
                 cs[tid] = make_double2(c, s);
@@ -205,10 +208,13 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
             if (tid == 0) __hip_atomic_store(&J.roundlog[nlog], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++nlog;
             any = true;
-            if (na * 2 <= half) {
-                // sparse round: only blocks in a rotating row or column change
-                for (int idx = tid; idx < na * half; idx += nthr) {
-                    const int ia = idx / half, b = idx - ia * half, a = act[ia];
+            if (VG_SPARSE_OK && na * 2 <= half) {
+                // sparse round: only blocks in a rotating row or column change.  (a, b) runs over half^2 with a
+                // cheap skip on isact[a] (for half == 64 a wave is exactly one row a, so the skip is wave-uniform);
+                // a block with both pairs rotating is done once, from its larger index.
+                for (int idx = tid; idx < half * half; idx += nthr) {
+                    const int a = idx / half, b = idx - a * half;
+                    if (!isact[a]) continue;
                     if (a == b) {
                         vg_block_diag(W, pq[a], cs[a].x, cs[a].y);
                     } else if (!isact[b] || a > b) {
@@ -292,6 +298,9 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
         if (status || !any) break;
         if (sweep == VG_EIG_MAXSWEEP - 1) status = VGGP_ENOCONV;
     }
+    // every storing wave drains its log stores BEFORE the barrier that precedes the DONE publication
+    // (__syncthreads() alone does not wait for vmcnt on gfx950)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int i = tid; i < m; i += nthr) J.lam[i] = W[vg_tri(i) + i];
     if (tid == 0) {
