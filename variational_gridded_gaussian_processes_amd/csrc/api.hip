@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -35,6 +36,13 @@ struct VgDim {
     int *roundlog = nullptr, *counters = nullptr, *status = nullptr;
     int gh_split = 1, max_rounds = 0;
     bool have_prev = false;
+};
+
+struct VgGraphKey {
+    const void* y = nullptr;
+    const void* payload = nullptr;
+    double yy = 0.0;
+    bool operator==(const VgGraphKey& o) const { return y == o.y && payload == o.payload && yy == o.yy; }
 };
 
 struct HostOut {            // pinned readback block
@@ -67,6 +75,13 @@ struct vggp_ctx {
     size_t misc_bytes = 0;
     double* sumsq_partial = nullptr;
     double* sumsq_out = nullptr;
+    // captured step graphs.  Capture is illegal on the legacy default stream, so when the caller passes stream 0 the
+    // step runs on `own_stream`, a BLOCKING stream: it is implicitly ordered with the legacy default stream in both
+    // directions (uploads / all-reduce issued by torch on stream 0 before, q(v) / posterior calls after).
+    hipStream_t own_stream = nullptr;
+    bool use_graph = true;
+    hipGraphExec_t gexec[5] = {};
+    VgGraphKey gkey[5];
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
     bool prof = false;
     hipEvent_t ev[VGGP_NSTAGE + 2] = {};
@@ -74,6 +89,8 @@ struct vggp_ctx {
     double prof_ms[VGGP_NSTAGE] = {};
     int prof_steps = 0;
 };
+
+static void graphs_clear(vggp_ctx* c);
 
 static const char* VG_STAGE_NAMES[VGGP_NSTAGE] = {
     "factor_build", "cholesky_inverse", "gemm_BV(Linv*[A|dA])", "gemm_gram+project(S=[B2;V2]Y)", "gemm_C(B1*S)",
@@ -112,6 +129,9 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
     vggp_ctx* c = new (std::nothrow) vggp_ctx();
     if (!c) { vg_set_error("out of host memory"); return VGGP_ENOMEM; }
     c->device = device;
+    const char* ng = getenv("VGGP_NO_GRAPH");
+    c->use_graph = !(ng && ng[0] == '1');
+    VG_HIP(hipStreamCreate(&c->own_stream));
     VG_HIP(hipHostMalloc((void**)&c->h_theta, 8 * sizeof(double), hipHostMallocDefault));
     VG_HIP(hipHostMalloc((void**)&c->h_out, sizeof(HostOut), hipHostMallocDefault));
     VG_HIP(hipMalloc((void**)&c->sumsq_partial, 1024 * sizeof(double)));
@@ -122,13 +142,15 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
 
 extern "C" int vggp_destroy(vggp_ctx* c) {
     if (!c) return VGGP_OK;
-    hipSetDevice(c->device);
-    if (c->arena) hipFree(c->arena);
-    if (c->misc) hipFree(c->misc);
-    if (c->h_theta) hipHostFree(c->h_theta);
-    if (c->h_out) hipHostFree(c->h_out);
-    if (c->sumsq_partial) hipFree(c->sumsq_partial);
-    if (c->sumsq_out) hipFree(c->sumsq_out);
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < 5; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->misc) (void)hipFree(c->misc);
+    if (c->h_theta) (void)hipHostFree(c->h_theta);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->sumsq_partial) (void)hipFree(c->sumsq_partial);
+    if (c->sumsq_out) (void)hipFree(c->sumsq_out);
     delete c;
     return VGGP_OK;
 }
@@ -241,6 +263,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     VG_REQUIRE(desc->n_total >= desc->n1 * desc->n2, "vggp_plan: n_total smaller than the local grid");
     VG_REQUIRE(desc->n1 < (1L << 24) && desc->n2 < (1L << 24), "vggp_plan: grid axis too long");
     c->planned = false;
+    graphs_clear(c);
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -281,25 +304,12 @@ extern "C" int64_t vggp_payload_len(const vggp_ctx* c) { return (c && c->planned
 extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t)c->arena_used : 0; }
 
 // ---------------------------------------------------------------------------------
-static int upload_theta(vggp_ctx* c, const double theta[5], hipStream_t st) {
-    for (int i = 0; i < 5; ++i) {
-        VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
-        c->h_theta[i] = theta[i];
-    }
+// Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
+// caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
+static int partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st) {
     VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
-    return VGGP_OK;
-}
-
-extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double theta[5], double* payload, void* stream) {
-    if (!c || !c->planned) { vg_set_error("vggp_elbo_partials: context not planned"); return VGGP_ESTATE; }
-    VG_REQUIRE(Y && theta && payload, "vggp_elbo_partials: null argument");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    int rc = upload_theta(c, theta, st);
-    if (rc) return rc;
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
-    if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
     VG_MARK(0);
 
     // 1. factor build (unit outputscale): A0|dA0, K0, dK0 for both dimensions
@@ -313,11 +323,16 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
 
     // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
     VgCholJob cj[2];
+    VgClearArgs clr;
+    clr.n = 0;
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        VG_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), st));
+        clr.ptr[clr.n] = d.status; clr.nwords[clr.n++] = 2;
+        clr.ptr[clr.n] = reinterpret_cast<int*>(d.chol_scratch); clr.nwords[clr.n++] = 16;     // jitter-level flags
+        clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 4;                                  // Jacobi progress word
         cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
     }
+    VG_HIP(vg_clear_launch(&clr, st));
     VG_HIP(vg_chol_launch(cj, 2, st));
     VG_MARK(2);
 
@@ -366,18 +381,11 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     vg_red_add(&r, c->CCslab, payload + 2 * m2 * m2, 3L * m1 * m2, cc_slab, cc_slabs);
     VG_HIP(vg_red_launch(&r, st));
     VG_MARK(6);
-    c->have_partials = true;
     return VGGP_OK;
 }
 
-extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_total, const double theta[5],
-                                double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
-    if (!c || !c->planned || !c->have_partials) { vg_set_error("vggp_elbo_finish: call vggp_elbo_partials first"); return VGGP_ESTATE; }
-    VG_REQUIRE(payload && theta && elbo_out && grad_out, "vggp_elbo_finish: null argument");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    int rc = upload_theta(c, theta, st);
-    if (rc) return rc;
+static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st) {
+    VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     const double* G0[2] = {d1.GH, payload};
@@ -387,7 +395,6 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
-    const bool warm = c->desc.warm_start && d1.have_prev && d2.have_prev;
     VgEigJob ej[2];
     if (warm) {
         vg_gemm_init(&g);
@@ -409,8 +416,7 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
         ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds};
     }
-    for (int k = 0; k < 2; ++k) VG_HIP(hipMemsetAsync(c->d[k].counters, 0, 4 * sizeof(int), st));
-    VG_HIP(vg_eigh_launch(ej, 2, st));
+    VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
     VG_MARK(9);
 
@@ -456,14 +462,60 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     VG_HIP(vg_final_launch(&ms, st));
     VG_MARK(14);
 
-    // 10. the only host sync of the step: 6 doubles + diagnostics
-    VG_HIP(hipMemcpyAsync(c->h_out->out, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    // 10. keep this step's basis for the next warm start / q(v) / posterior, and stage the 6 result doubles +
+    //     diagnostics to pinned host memory (read after the step's only host sync)
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
+        VG_HIP(hipMemcpyAsync(d.QtPrev, d.Qt, sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
         VG_HIP(hipMemcpyAsync(&c->h_out->jitter[k], d.jitter, sizeof(double), hipMemcpyDeviceToHost, st));
         VG_HIP(hipMemcpyAsync(c->h_out->counters[k], d.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         VG_HIP(hipMemcpyAsync(&c->h_out->status[k], d.status, sizeof(int), hipMemcpyDeviceToHost, st));
     }
+    VG_HIP(hipMemcpyAsync(c->h_out->out, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    return VGGP_OK;
+}
+
+// ---- HIP-graph cache: the launch sequence of a step is fixed for a plan, so it is captured once per
+// (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
+enum { VG_G_PARTIALS = 0, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_STEP_COLD, VG_G_STEP_WARM, VG_G_COUNT };
+
+static void graphs_clear(vggp_ctx* c) {
+    for (int i = 0; i < VG_G_COUNT; ++i) {
+        if (c->gexec[i]) { (void)hipGraphExecDestroy(c->gexec[i]); c->gexec[i] = nullptr; }
+        c->gkey[i] = VgGraphKey();
+    }
+}
+
+template <typename F>
+static int run_graph(vggp_ctx* c, int which, const VgGraphKey& key, hipStream_t st, F enqueue) {
+    if (!c->use_graph || c->prof) return enqueue();
+    if (!c->gexec[which] || !(c->gkey[which] == key)) {
+        if (c->gexec[which]) { (void)hipGraphExecDestroy(c->gexec[which]); c->gexec[which] = nullptr; }
+        VG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue();
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { vg_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return VGGP_EHIP; }
+        const hipError_t ei = hipGraphInstantiate(&c->gexec[which], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { c->gexec[which] = nullptr; vg_set_error("hipGraphInstantiate -> %s", hipGetErrorString(ei)); return VGGP_EHIP; }
+        c->gkey[which] = key;
+    }
+    VG_HIP(hipGraphLaunch(c->gexec[which], st));
+    return VGGP_OK;
+}
+
+static int set_theta(vggp_ctx* c, const double theta[5]) {
+    for (int i = 0; i < 5; ++i) {
+        VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
+        c->h_theta[i] = theta[i];
+    }
+    return VGGP_OK;
+}
+
+// host side of the end of a step: the only synchronisation, then unpack the pinned block
+static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vggp_info* info, hipStream_t st) {
     VG_HIP(hipStreamSynchronize(st));
     if (c->prof && c->ev_set[0] && c->ev_set[14]) {
         // stage i spans event slot i -> i+1, except stage 6 (warm-start GEMMs) which starts at the finish marker
@@ -489,22 +541,60 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     }
     if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
     if (status == VGGP_ENOCONV) { vg_set_error("Jacobi eigensolver did not converge"); return VGGP_ENOCONV; }
-    // keep this step's basis for the next warm start
-    for (int k = 0; k < 2; ++k) {
-        VgDim& d = c->d[k];
-        std::swap(d.Qt, d.QtPrev);      // QtPrev now holds the fresh basis; Qt is scratch until the next step
-        d.have_prev = true;
-    }
+    for (int k = 0; k < 2; ++k) c->d[k].have_prev = true;      // QtPrev holds this step's basis
     c->have_step = true;
     return VGGP_OK;
+}
+
+extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double theta[5], double* payload, void* stream) {
+    if (!c || !c->planned) { vg_set_error("vggp_elbo_partials: context not planned"); return VGGP_ESTATE; }
+    VG_REQUIRE(Y && theta && payload, "vggp_elbo_partials: null argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    int rc = set_theta(c, theta);
+    if (rc) return rc;
+    if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
+    const VgGraphKey key{Y, payload, 0.0};
+    rc = run_graph(c, VG_G_PARTIALS, key, st, [&] { return partials_enqueue(c, Y, payload, st); });
+    if (rc) return rc;
+    c->have_partials = true;
+    return VGGP_OK;
+}
+
+extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_total, const double theta[5],
+                                double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
+    if (!c || !c->planned || !c->have_partials) { vg_set_error("vggp_elbo_finish: call vggp_elbo_partials first"); return VGGP_ESTATE; }
+    VG_REQUIRE(payload && theta && elbo_out && grad_out, "vggp_elbo_finish: null argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    int rc = set_theta(c, theta);
+    if (rc) return rc;
+    const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
+    const VgGraphKey key{nullptr, payload, yy_total};
+    rc = run_graph(c, warm ? VG_G_FINISH_WARM : VG_G_FINISH_COLD, key, st,
+                   [&] { return finish_enqueue(c, payload, yy_total, warm, st); });
+    if (rc) return rc;
+    return finish_collect(c, elbo_out, grad_out, info, st);
 }
 
 extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
                               double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step: context not planned"); return VGGP_ESTATE; }
-    int rc = vggp_elbo_partials(c, Y, theta, c->payload, stream);
+    VG_REQUIRE(Y && theta && elbo_out && grad_out, "vggp_elbo_step: null argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    int rc = set_theta(c, theta);
     if (rc) return rc;
-    return vggp_elbo_finish(c, c->payload, yy_total, theta, elbo_out, grad_out, info, stream);
+    if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
+    const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
+    const VgGraphKey key{Y, c->payload, yy_total};
+    rc = run_graph(c, warm ? VG_G_STEP_WARM : VG_G_STEP_COLD, key, st, [&] {
+        const int r1 = partials_enqueue(c, Y, c->payload, st);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st);
+    });
+    if (rc) return rc;
+    c->have_partials = true;
+    return finish_collect(c, elbo_out, grad_out, info, st);
 }
 
 // ---------------------------------------------------------------------------------
@@ -660,7 +750,11 @@ extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, do
     double* scratch = (double*)c->misc;
     double* jit = scratch + m * (m + 1);
     int* status = (int*)(jit + 2);
-    VG_HIP(hipMemsetAsync(jit, 0, 8 * sizeof(double), st));
+    VgClearArgs clr;
+    clr.n = 2;
+    clr.ptr[0] = reinterpret_cast<int*>(jit); clr.nwords[0] = 16;
+    clr.ptr[1] = reinterpret_cast<int*>(scratch); clr.nwords[1] = 16;
+    VG_HIP(vg_clear_launch(&clr, st));
     VgCholJob j{K, L, Linv, scratch, jit, status, (int)m};
     VG_HIP(vg_chol_launch(&j, 1, st));
     double hj = 0.0;
@@ -689,7 +783,10 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     int* roundlog = (int*)p; p += (size_t)max_rounds * 4;
     p = (char*)(((uintptr_t)p + 63) & ~uintptr_t(63));
     int* counters = (int*)p;
-    VG_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+    VgClearArgs clr;
+    clr.n = 1;
+    clr.ptr[0] = counters; clr.nwords[0] = 4;
+    VG_HIP(vg_clear_launch(&clr, st));
     VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds};
     VG_HIP(vg_eigh_launch(&j, 1, st));
     int hc[4] = {0, 0, 0, 0};

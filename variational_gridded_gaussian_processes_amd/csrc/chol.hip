@@ -35,7 +35,7 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
     const int m = J.m;
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     const double jit = VG_JITTERS[lvl];
-    int* flags = reinterpret_cast<int*>(J.scratch);          // [4] per matrix, zeroed by the launcher
+    int* flags = reinterpret_cast<int*>(J.scratch);          // [4] per matrix, zeroed by the CALLER before the launch
 
     double a[MT][MT];
     int trow[MT], tcol[MT];                                    // packed-row offsets of my rows / of my columns' rows
@@ -288,8 +288,6 @@ hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
         if (a.fast[j]) {
             const size_t need = (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double);
             if (need > lds) lds = need;
-            hipError_t e = hipMemsetAsync(jobs[j].scratch, 0, 64, st);      // level flags
-            if (e != hipSuccess) return e;
         }
     }
     hipLaunchKernelGGL(vg_chol_kernel, dim3(4, njobs), dim3(1024), lds, st, a);

@@ -146,6 +146,12 @@ struct VgMspace {
 hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st);
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st);
 
+// zero a handful of small device buffers with ONE kernel (used instead of hipMemsetAsync: memset nodes of a
+// captured graph were observed to replay with a wrong fill value after an unrelated hipMalloc on ROCm 7.2)
+#define VG_CLEAR_MAX 8
+struct VgClearArgs { int* ptr[VG_CLEAR_MAX]; int nwords[VG_CLEAR_MAX]; int n; };
+hipError_t vg_clear_launch(const VgClearArgs* a, hipStream_t st);
+
 // q(v) / posterior helpers
 hipError_t vg_scale_sq_launch(const double* in, double* out_sq, long n, hipStream_t st);
 hipError_t vg_qv_weights_launch(const double* theta, const double* beta, const double* invD, double* w_mean,

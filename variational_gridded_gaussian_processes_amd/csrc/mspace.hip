@@ -255,3 +255,14 @@ hipError_t vg_sumsq_launch(const double* y, long n, double* partial, double* out
     hipLaunchKernelGGL(vg_sumsq_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, out);
     return hipGetLastError();
 }
+
+__global__ void vg_clear_kernel(const VgClearArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.n)
+        for (int i = threadIdx.x; i < a.nwords[b]; i += blockDim.x) a.ptr[b][i] = 0;
+}
+hipError_t vg_clear_launch(const VgClearArgs* a, hipStream_t st) {
+    if (a->n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(vg_clear_kernel, dim3(a->n), dim3(64), 0, st, *a);
+    return hipGetLastError();
+}
