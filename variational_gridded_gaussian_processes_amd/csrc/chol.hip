@@ -5,17 +5,18 @@
 // N x N dense matrices.  The explicit L^{-1} turns every later triangular solve into an MFMA GEMM (validated
 // against substitution in DESIGN.md: <= 1e-8 relative on the ill-conditioned RBF factors with the 1e-8 jitter).
 //
-// Fast path (m <= 184), one workgroup of 1024 threads per (matrix, jitter level):
+// Fast path (m <= 128), one workgroup of 1024 threads per (matrix, jitter level):
 //   * the four jitter levels (0, 1e-8, 1e-7, 1e-6) are factored CONCURRENTLY by four workgroups; the lowest
 //     level that succeeds wins (identical to trying them in order) and only the winner computes the inverse and
 //     writes the outputs.  A near-singular RBF factor therefore costs one factorisation latency, not two.
-//   * register-resident right-looking Cholesky: thread (ty, tx) owns the trailing-matrix elements
-//     (ty + 32a, tx + 32b) for the whole factorisation; only the pivot column travels through LDS (packed lower
+//   * register-resident right-looking Cholesky: thread (ty, tx) of a 32 x 32 grid owns the trailing-matrix
+//     elements (ty + 32a, tx + 32b) for the whole factorisation (4 waves per SIMD keep the f64 pipe busy: a lone
+//     wave issues one f64 FMA per ~8 cycles); only the pivot column travels through LDS (packed lower
 //     triangle), so a column step is one barrier + 2*MT LDS reads + MT^2 FMAs instead of a serial chain of LDS
 //     read-modify-writes.
 //   * L^{-1} by forward elimination on the identity, same ownership: per step the finished row k is broadcast
 //     through a double-buffered LDS row, every thread updates its own elements in registers.
-// Generic path (m > 184): the matrix lives in an L2-resident global scratch, one workgroup tries the levels in
+// Generic path (m > 128): the matrix lives in an L2-resident global scratch, one workgroup tries the levels in
 // order (slow; only used by the building-block API for large matrices).
 #include "common.h"
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ int vg_ctri(int i) { return (i * (i + 1)) >> 1; }
 template <int MT>
 __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd, double* rowbuf, int* s_i) {
     const int m = J.m;
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;      // 32 x 32 threads, each owns MT x MT elements
     const double jit = VG_JITTERS[lvl];
     int* flags = reinterpret_cast<int*>(J.scratch);          // [4] per matrix, zeroed by the CALLER before the launch
 
@@ -50,31 +51,49 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
         }
     }
 
+#ifdef VG_CHOL_STAMP
+    unsigned long long tA = 0, tB = 0, tC = 0, s0, s1, tstart, tend;
+#define CS(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    CS(tstart);
+#else
+#define CS(var)
+#endif
     bool ok = true;
     int pivoff = 0;
     for (int k = 0; k < m; ++k) {
+#ifdef VG_CHOL_STAMP
+        CS(s0);
+#endif
         const int kb = k >> 5, kx = k & 31;
         if (tx == kx) {                                       // owners of column k publish it (rows >= k)
-#pragma unroll
-            for (int ib = 0; ib < MT; ++ib)
-                if (ib == kb) {
-#pragma unroll
-                    for (int ia = 0; ia < MT; ++ia) {
-                        const int i = ty + 32 * ia;
-                        if (i >= k && i < m) W[trow[ia] + k] = a[ia][ib];
-                    }
-                }
+            // kb is wave-uniform: a branch chain over compile-time column indices keeps a[][] statically indexed
+            // (a select chain over all MT columns costs hundreds of cycles per step)
+#define VG_PUB(KB)                                                                  \
+    if (KB < MT && kb == KB) {                                                      \
+        _Pragma("unroll") for (int ia = 0; ia < MT; ++ia)                           \
+            if (ty + 32 * ia >= k) W[trow[ia] + k] = a[ia][KB < MT ? KB : 0];       \
+    }
+            VG_PUB(0) else VG_PUB(1) else VG_PUB(2) else VG_PUB(3)
+#undef VG_PUB
         }
+#ifdef VG_CHOL_STAMP
+        CS(s1); tA += s1 - s0;
+#endif
         __syncthreads();
-        // all LDS reads of the step are issued together (pivot, my rows' and my columns' entries of column k)
+#ifdef VG_CHOL_STAMP
+        CS(s0); tB += s0 - s1;
+#endif
+        // all LDS reads of the step are issued together (pivot, my rows' and my columns' entries of column k).
+        // No predication: for i <= k or j <= k the values read are stale/garbage, but they only ever touch
+        // registers of already-published columns or of the unused upper triangle (L is taken from LDS, never from
+        // these registers), so they are don't-cares.  The LDS tile is sized for the padded 16*MT matrix.
         const double piv = W[pivoff];
         pivoff += k + 2;                                      // tri(k+1) + (k+1)
         double li[MT], lj[MT];
 #pragma unroll
         for (int ia = 0; ia < MT; ++ia) {
-            const int i = ty + 32 * ia, j = tx + 32 * ia;
-            li[ia] = (i > k && i < m) ? W[trow[ia] + k] : 0.0;
-            lj[ia] = (j > k && j < m) ? W[tcol[ia] + k] : 0.0;
+            li[ia] = W[trow[ia] + k];
+            lj[ia] = W[tcol[ia] + k];
         }
         if (!(piv > 0.0) || !(piv < 1.0e300)) { ok = false; break; }      // uniform
         double rp = __builtin_amdgcn_rcp(piv);                // 1/piv: hardware seed + 2 Newton steps
@@ -86,7 +105,17 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
 #pragma unroll
             for (int ib = 0; ib < MT; ++ib) a[ia][ib] -= lr * lj[ib];
         }
+#ifdef VG_CHOL_STAMP
+        CS(s1); tC += s1 - s0;
+#endif
     }
+#ifdef VG_CHOL_STAMP
+    CS(tend);
+    if ((tid & 63) == 0 && lvl == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(J.scratch) + 16 + (tid >> 6) * 4;
+        dbg[0] = tA; dbg[1] = tB; dbg[2] = tC; dbg[3] = tend - tstart;
+    }
+#endif
 
     // ---- level selection: the lowest successful level wins (relaxed agent-scope flags, no payload) ----------
     __syncthreads();
@@ -137,26 +166,25 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
     for (int k = 0; k < m; ++k) {
         const int ka = k >> 5, ky = k & 31;
         double* rb = rowbuf + (k & 1) * 192;
-        if (ty == ky) {                                       // owners of row k: finish it and broadcast
+        if (ty == ky) {                                       // owners of row k: finish it and broadcast (zeros beyond k)
             const double rk = rsd[k];                         // 1 / L[k][k]
-#pragma unroll
-            for (int ia = 0; ia < MT; ++ia)
-                if (ia == ka) {
-#pragma unroll
-                    for (int ib = 0; ib < MT; ++ib) {
-                        const int j = tx + 32 * ib;
-                        a[ia][ib] *= rk;
-                        if (j <= k) rb[j] = a[ia][ib];
-                    }
-                }
+#define VG_PUBR(KA)                                                                 \
+    if (KA < MT && ka == KA) {                                                      \
+        _Pragma("unroll") for (int ib = 0; ib < MT; ++ib) {                         \
+            a[KA < MT ? KA : 0][ib] *= rk;                                          \
+            rb[tx + 32 * ib] = a[KA < MT ? KA : 0][ib];                             \
+        }                                                                           \
+    }
+            VG_PUBR(0) else VG_PUBR(1) else VG_PUBR(2) else VG_PUBR(3)
+#undef VG_PUBR
         }
         __syncthreads();
         double li[MT], xr[MT];
 #pragma unroll
         for (int ia = 0; ia < MT; ++ia) {
-            const int i = ty + 32 * ia, j = tx + 32 * ia;
-            li[ia] = (i > k && i < m) ? W[trow[ia] + k] : 0.0;
-            xr[ia] = (j <= k) ? rb[j] : 0.0;
+            const int i = ty + 32 * ia;
+            li[ia] = (i > k) ? W[trow[ia] + k] : 0.0;         // finished rows (i <= k) must stay untouched
+            xr[ia] = rb[tx + 32 * ia];
         }
 #pragma unroll
         for (int ia = 0; ia < MT; ++ia)
@@ -262,14 +290,14 @@ __global__ __launch_bounds__(1024) void vg_chol_kernel(const VgCholArgs a) {
     const VgCholJob& J = a.job[blockIdx.y];
     const int lvl = blockIdx.x;
     if (a.fast[blockIdx.y]) {
-        if (J.m <= 128) vg_chol_fast<4>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
-        else vg_chol_fast<6>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
+        if (J.m <= 64) vg_chol_fast<2>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
+        else vg_chol_fast<4>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
     } else if (lvl == 0) {
         vg_chol_generic(J, sd);
     }
 }
 
-static const int VG_CHOL_FAST_MAX_M = 184;      // packed triangle in LDS: 184*185/2*8 B = 136 KB
+static const int VG_CHOL_FAST_MAX_M = 128;      // 4 x 4 register tile per thread; LDS holds the padded packed triangle
 
 hipError_t vg_chol_setup() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_chol_kernel),
@@ -286,7 +314,8 @@ hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
         if (jobs[j].m > 1024 || jobs[j].m < 1) return hipErrorInvalidValue;
         a.fast[j] = jobs[j].m <= VG_CHOL_FAST_MAX_M;
         if (a.fast[j]) {
-            const size_t need = (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double);
+            const size_t mp = jobs[j].m <= 64 ? 64 : 128;
+            const size_t need = mp * (mp + 1) / 2 * sizeof(double);
             if (need > lds) lds = need;
         }
     }
