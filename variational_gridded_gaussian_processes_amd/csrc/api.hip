@@ -62,7 +62,7 @@ struct vggp_ctx {
     // cross-dimension buffers
     double *St = nullptr, *CCslab = nullptr, *payload = nullptr, *GH1 = nullptr;
     double *T3 = nullptr, *P3 = nullptr, *beta = nullptr, *bl2 = nullptr, *bl1 = nullptr, *invD = nullptr;
-    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
+    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
     double *out = nullptr, *theta = nullptr, *wq = nullptr;
     int st_split = 1, cc_split = 1;
     long payload_len = 0;
@@ -231,6 +231,9 @@ static void layout(vggp_ctx* c, Bump& b) {
     c->rowpart = b.take<double>(m1 * 8);
     c->r1 = b.take<double>(m1);
     c->r1l = b.take<double>(m1);
+    c->r2 = b.take<double>(m2);
+    c->r2l = b.take<double>(m2);
+    c->dotpart = b.take<double>(64 * 4);
     c->X1 = b.take<double>(m1 * m1);
     c->X1l = b.take<double>(m1 * m1);
     c->X2 = b.take<double>(m2 * m2);
@@ -449,6 +452,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     ms.X1 = c->X1; ms.X1l = c->X1l; ms.X2 = c->X2; ms.X2l = c->X2l;
     ms.beta = c->beta; ms.bl2 = c->bl2; ms.bl1 = c->bl1; ms.invD = c->invD;
     ms.rowpart = c->rowpart; ms.r1 = c->r1; ms.r1l = c->r1l; ms.out = c->out;
+    ms.r2 = c->r2; ms.r2l = c->r2l; ms.dotpart = c->dotpart;
     ms.m1 = (int)m1; ms.m2 = (int)m2; ms.n_total = (double)c->desc.n_total; ms.yy = yy_total;
     VG_HIP(vg_dstage_launch(&ms, st));
     VG_MARK(12);

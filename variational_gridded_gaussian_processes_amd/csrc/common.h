@@ -137,6 +137,9 @@ struct VgMspace {
     double* rowpart;         // [m1][8] per-row partial scalars
     double* r1;              // [m1] sum_i2 1/D
     double* r1l;             // [m1] sum_i2 lam2/D
+    double* r2;              // [m2] sum_i1 1/D        (vg_partial_kernel)
+    double* r2l;             // [m2] sum_i1 lam1/D
+    double* dotpart;         // [64][4] slices of sum(E1 o X1), sum(F1 o X1l), sum(E2 o X2), sum(F2 o X2l)
     // outputs
     double* out;             // [8]: elbo, g_ell1, g_ell2, g_s1, g_s2, g_v, -, -
     int m1, m2;

@@ -74,14 +74,51 @@ hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---- final reduction: one workgroup ------------------------------------------------
-struct VgDimSums { double se, ser, sfr, sf, sel, EX, FX; };
+// ---- final reduction in two launches -----------------------------------------------------------------------------
+// (1) vg_partial_kernel, VG_NPART workgroups: column sums of 1/D and lam1/D, and slices of the four m x m dot
+//     products sum(E o X), sum(F o Xl) per dimension;  (2) vg_final_kernel, one workgroup: O(m) combinations only.
+#define VG_NPART 64
 
-__device__ VgDimSums vg_dim_sums(const double* E, const double* F, const double* X, const double* Xl,
-                                 const double* lam0, double s, const double* r, const double* rl, int m,
-                                 double* red) {
+__global__ __launch_bounds__(256) void vg_partial_kernel(const VgMspace ms) {
+    __shared__ double red[16];
+    const int m1 = ms.m1, m2 = ms.m2, b = blockIdx.x;
+    const double s1 = ms.theta[2];
+    // column sums: block b owns columns b, b + VG_NPART, ...
+    for (int i2 = b; i2 < m2; i2 += VG_NPART) {
+        double a = 0.0, c = 0.0;
+        for (int i1 = threadIdx.x; i1 < m1; i1 += blockDim.x) {
+            const double iD = ms.invD[(long)i1 * m2 + i2];
+            a += iD;
+            c += s1 * ms.lam1[i1] * iD;
+        }
+        a = vg_block_sum(a, red);
+        c = vg_block_sum(c, red);
+        if (threadIdx.x == 0) { ms.r2[i2] = a; ms.r2l[i2] = c; }
+    }
+    // dot-product slices
+    double ex1 = 0, fx1 = 0, ex2 = 0, fx2 = 0;
+    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m1 * m1; idx += (long)VG_NPART * blockDim.x) {
+        ex1 += ms.E1[idx] * ms.X1[idx];
+        fx1 += ms.F1[idx] * ms.X1l[idx];
+    }
+    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m2 * m2; idx += (long)VG_NPART * blockDim.x) {
+        ex2 += ms.E2[idx] * ms.X2[idx];
+        fx2 += ms.F2[idx] * ms.X2l[idx];
+    }
+    ex1 = vg_block_sum(ex1, red); fx1 = vg_block_sum(fx1, red);
+    ex2 = vg_block_sum(ex2, red); fx2 = vg_block_sum(fx2, red);
+    if (threadIdx.x == 0) {
+        ms.dotpart[b * 4 + 0] = ex1; ms.dotpart[b * 4 + 1] = fx1;
+        ms.dotpart[b * 4 + 2] = ex2; ms.dotpart[b * 4 + 3] = fx2;
+    }
+}
+
+struct VgDimSums { double se, ser, sfr, sf, sel; };
+
+__device__ VgDimSums vg_dim_sums(const double* E, const double* F, const double* lam0, double s, const double* r,
+                                 const double* rl, int m, double* red) {
     VgDimSums o;
-    double se = 0, ser = 0, sfr = 0, sf = 0, sel = 0, EX = 0, FX = 0;
+    double se = 0, ser = 0, sfr = 0, sf = 0, sel = 0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         const double e = E[(long)i * m + i], f = 2.0 * s * F[(long)i * m + i];
         se += e;
@@ -90,39 +127,19 @@ __device__ VgDimSums vg_dim_sums(const double* E, const double* F, const double*
         sf += f;
         sel += e * s * lam0[i];
     }
-    for (long idx = threadIdx.x; idx < (long)m * m; idx += blockDim.x) {
-        EX += E[idx] * X[idx];
-        FX += F[idx] * Xl[idx];
-    }
     o.se = vg_block_sum(se, red);
     o.ser = vg_block_sum(ser, red);
     o.sfr = vg_block_sum(sfr, red);
     o.sf = vg_block_sum(sf, red);
     o.sel = vg_block_sum(sel, red);
-    o.EX = vg_block_sum(EX, red);
-    o.FX = 2.0 * s * vg_block_sum(FX, red);
     return o;
 }
 
-__global__ __launch_bounds__(1024) void vg_final_kernel(const VgMspace ms) {
+__global__ __launch_bounds__(256) void vg_final_kernel(const VgMspace ms) {
     __shared__ double red[16];
-    __shared__ double r2[1024], r2l[1024];
     const int m1 = ms.m1, m2 = ms.m2;
     const double s1 = ms.theta[2], s2 = ms.theta[3], v = ms.theta[4];
     const double N = ms.n_total, yy = ms.yy;
-
-    // column sums of 1/D and lam1/D
-    for (int i2 = threadIdx.x; i2 < m2; i2 += blockDim.x) {
-        double a = 0.0, b = 0.0;
-        for (int i1 = 0; i1 < m1; ++i1) {
-            const double iD = ms.invD[(long)i1 * m2 + i2];
-            a += iD;
-            b += s1 * ms.lam1[i1] * iD;
-        }
-        r2[i2] = a;
-        r2l[i2] = b;
-    }
-    __syncthreads();
 
     double S[7];
 #pragma unroll
@@ -131,20 +148,28 @@ __global__ __launch_bounds__(1024) void vg_final_kernel(const VgMspace ms) {
         for (int i = threadIdx.x; i < m1; i += blockDim.x) t += ms.rowpart[i * 8 + q];
         S[q] = vg_block_sum(t, red);
     }
+    double dp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double t = 0.0;
+        for (int i = threadIdx.x; i < VG_NPART; i += blockDim.x) t += ms.dotpart[i * 4 + q];
+        dp[q] = vg_block_sum(t, red);
+    }
     double t1 = 0.0, t2 = 0.0;
     for (int i = threadIdx.x; i < m1; i += blockDim.x) t1 += ms.lam1[i];
     for (int i = threadIdx.x; i < m2; i += blockDim.x) t2 += ms.lam2[i];
     const double sl1 = s1 * vg_block_sum(t1, red), sl2 = s2 * vg_block_sum(t2, red);
 
-    const VgDimSums d1 = vg_dim_sums(ms.E1, ms.F1, ms.X1, ms.X1l, ms.lam1, s1, ms.r1, ms.r1l, m1, red);
-    const VgDimSums d2 = vg_dim_sums(ms.E2, ms.F2, ms.X2, ms.X2l, ms.lam2, s2, r2, r2l, m2, red);
+    const VgDimSums d1 = vg_dim_sums(ms.E1, ms.F1, ms.lam1, s1, ms.r1, ms.r1l, m1, red);
+    const VgDimSums d2 = vg_dim_sums(ms.E2, ms.F2, ms.lam2, s2, ms.r2, ms.r2l, m2, red);
+    const double EX1 = dp[0], FX1 = 2.0 * s1 * dp[1], EX2 = dp[2], FX2 = 2.0 * s2 * dp[3];
 
     if (threadIdx.x == 0) {
         const double v2 = v * v;
         const double elbo = -0.5 * (N * 1.8378770664093453 + N * log(v) + S[0] + yy / v - S[1] / v2)
                             - (N * s1 * s2 - sl1 * sl2) / (2.0 * v);
-        const double quad1 = 2.0 * S[5] - d1.EX - d1.FX / v;
-        const double quad2 = 2.0 * S[6] - d2.EX - d2.FX / v;
+        const double quad1 = 2.0 * S[5] - EX1 - FX1 / v;
+        const double quad2 = 2.0 * S[6] - EX2 - FX2 / v;
         const double g_l1 = -0.5 * (d1.ser + d1.sfr / v - (double)m2 * d1.se - quad1 / v2)
                             + sl2 / (2.0 * v) * (d1.sf - d1.sel);
         const double g_l2 = -0.5 * (d2.ser + d2.sfr / v - (double)m1 * d2.se - quad2 / v2)
@@ -164,7 +189,10 @@ __global__ __launch_bounds__(1024) void vg_final_kernel(const VgMspace ms) {
 }
 
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st) {
-    hipLaunchKernelGGL(vg_final_kernel, dim3(1), dim3(1024), 0, st, *ms);
+    hipLaunchKernelGGL(vg_partial_kernel, dim3(VG_NPART), dim3(256), 0, st, *ms);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(vg_final_kernel, dim3(1), dim3(256), 0, st, *ms);
     return hipGetLastError();
 }
 
