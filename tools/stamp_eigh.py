@@ -11,12 +11,11 @@ d = Kr.dim_prepare(f, 0.2, 1.0)
 G = torch.tensor(d.B @ d.B.T, device="cuda")
 e = Engine(0)
 lam, Qt, sw = e.eigh(G)
-buf = (C.c_uint64 * 64)()
+buf = (C.c_uint64 * 128)()
 e.lib.vggp_debug_read_misc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-print(e.lib.vggp_debug_read_misc(e._h, buf, 64 * 8))
-a = np.array(list(buf)).reshape(16, 4)
-rounds = sw * 127
-print("sweeps", sw, "rounds(total)", rounds)
-print("per-round s_memtime ticks, wave: [P, barrier1, U, barrier2]")
-for w in (0, 1, 7, 15):
-    print(w, (a[w] / rounds).round(1), "sum", round(a[w].sum() / rounds, 1))
+print(e.lib.vggp_debug_read_misc(e._h, buf, 128 * 8))
+a = np.array(list(buf)).reshape(16, 8).astype(float)
+print("sweeps", sw)
+for w in (0, 1, 4, 15):
+    nin, nout = a[w, 6], a[w, 7]
+    print("wave", w, "inner rounds", int(nin), "outer", int(nout), "per inner [P, bar1, U, bar2]:", (a[w, :4] / nin).round(0), "per outer [gather, apply]:", (a[w, 4:6] / nout).round(0), "total Mcycles", round(a[w, :6].sum() / 1e6, 2))

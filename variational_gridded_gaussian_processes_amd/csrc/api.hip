@@ -209,7 +209,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.gwork = b.take<double>(m2e * (m2e + 1));
         d.jitter = b.take<double>(2);
         d.max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
-        d.rotlog = b.take<double2>((size_t)d.max_rounds * (m2e / 2));
+        d.rotlog = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
         d.roundlog = b.take<int>(d.max_rounds);
         d.counters = b.take<int>(4);
         d.status = b.take<int>(2);
@@ -417,7 +417,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
-                         d.counters, d.m, d.max_rounds};
+                         d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m)};
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -778,12 +778,13 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     hipStream_t st = (hipStream_t)stream;
     const long m2e = m + (m & 1);
     const int max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
-    const size_t need = (size_t)m2e * (m2e + 1) * 8 + (size_t)max_rounds * (m2e / 2) * 16 + (size_t)max_rounds * 4 + 256;
+    const size_t logb = (vg_eigh_log_bytes((int)m) + 15) & ~size_t(15);
+    const size_t need = (size_t)m2e * (m2e + 1) * 8 + logb + (size_t)max_rounds * 4 + 256;
     int rc = ensure_misc(c, need);
     if (rc) return rc;
     char* p = (char*)c->misc;
     double* gwork = (double*)p; p += (size_t)m2e * (m2e + 1) * 8;
-    double2* rotlog = (double2*)p; p += (size_t)max_rounds * (m2e / 2) * 16;
+    double2* rotlog = (double2*)p; p += logb;
     int* roundlog = (int*)p; p += (size_t)max_rounds * 4;
     p = (char*)(((uintptr_t)p + 63) & ~uintptr_t(63));
     int* counters = (int*)p;
@@ -791,7 +792,7 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     clr.n = 1;
     clr.ptr[0] = counters; clr.nwords[0] = 4;
     VG_HIP(vg_clear_launch(&clr, st));
-    VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds};
+    VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds, (long)logb};
     VG_HIP(vg_eigh_launch(&j, 1, st));
     int hc[4] = {0, 0, 0, 0};
     VG_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));

@@ -110,7 +110,9 @@ struct VgEigJob {
     int* counters;        // [4]: nlog, sweeps, status, pad
     int m;
     int max_rounds;
+    long log_bytes;       // size of the rotlog buffer in bytes (vg_eigh_log_bytes(m))
 };
+size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);
 hipError_t vg_eigh_setup();
 

@@ -15,6 +15,9 @@
 #include "common.h"
 
 #define VG_EIG_TOL 1e-13
+#ifndef VG_BJ_MAX_M
+#define VG_BJ_MAX_M 128            // block Jacobi up to this size, scalar cyclic Jacobi beyond
+#endif
 #define VG_EIG_DONE (1 << 30)   // progress word: rounds published | DONE
 #define VG_EIG_LAG 9             // rounds whose log stores may still be in flight: vmcnt(16) with >= 2 VMEM ops per storing wave per round, +1
 #ifndef VG_SPARSE_OK
@@ -415,6 +418,323 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
     }
 }
 
+// =====================================================================================================================
+// Block Jacobi (m <= 128): the same m-1 rotation rounds per sweep, but organised so that every round works on 32 x 32
+// data instead of the whole matrix, and the long-range part of the update is dense f64 MFMA work.
+//   * indices are grouped in nb = 2 ceil(m/32) blocks of 16; an OUTER round pairs the blocks round-robin (nb/2 pairs);
+//   * each pair (I, J) is a 32 x 32 sub-problem S = G[IJ, IJ], gathered to LDS and rotated by a 4-wave group:
+//     outer round 0 does a full 31-round sweep of S (this is where within-block pairs are annihilated, every block is
+//     in exactly one pair), outer rounds >= 1 only the 16 rounds of cross pairs (i in I, j in J).  Rotations are
+//     accumulated into U (32 x 32, U <- U J);
+//   * afterwards the off-diagonal super-blocks are updated with MFMA, G_ab <- U_a^T G_ab U_b (the first product's
+//     accumulator tile is, register for register, the B operand of the second), the diagonal ones are S itself;
+//   * the four U of an outer round are logged (write-through) for the replay workgroups, which apply
+//     Qt[IJ, cols] <- U^T Qt[IJ, cols] with MFMA on their 16-column tile.
+// Per outer sweep: 31 + 16 (nb - 2) = m-ish inner rounds, each ~4x cheaper than a full-matrix round, plus nb - 1 applies.
+typedef double vg_bd4 __attribute__((ext_vector_type(4)));
+#define VG_BJ_LD 33
+#define VG_BJ_SLOT (2 * 32 * VG_BJ_LD)          // doubles per pair slot: S then U
+#define VG_BJ_MAXSWEEP 30
+
+__device__ __forceinline__ int vg_bgidx(int I, int Jb, int l) { return ((l < 16) ? I : Jb) * 16 + (l & 15); }
+
+__device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgPairRec* pq, int* flags, double* red) {
+    const int m = J.m;
+    const int nb = 2 * ((m + 31) / 32), Mp = 16 * nb, npair = nb >> 1;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid >> 8, lt = tid & 255;
+    double* Gp = dyn;                                            // packed lower triangle of the padded matrix
+    double* slots = dyn + ((Mp * (Mp + 1) / 2 + 1) & ~1);
+    double* S = slots + grp * VG_BJ_SLOT;
+    double* U = S + 32 * VG_BJ_LD;
+
+    double ss = 0.0;
+    for (int idx = tid; idx < Mp * Mp; idx += nthr) {
+        const int i = idx / Mp, j = idx - i * Mp;
+        if (j > i) continue;
+        const double v = (i < m && j < m) ? J.G[i * m + j] : 0.0;
+        Gp[vg_tri(i) + j] = v;
+        ss += (i == j) ? v * v : 2.0 * v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    double fro = 0.0;
+    for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
+    const double thr = VG_EIG_TOL * sqrt(fro) / (double)m;
+
+    // capacity of the log buffer in outer rounds (it was sized for the scalar kernel's (c, s) log)
+    const int cap_rounds = (int)(J.log_bytes / ((long)npair * 1024 * sizeof(double)));
+    double* ulog = reinterpret_cast<double*>(J.rotlog);
+
+#ifdef VG_EIG_STAMP
+    unsigned long long tP = 0, tB1 = 0, tU = 0, tB2 = 0, tG = 0, tA = 0, t0s, t1s, nin_tot = 0, nout = 0;
+#define BST(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BST(var)
+#endif
+    int nlog = 0, sweeps = 0, status = 0;
+    for (int sweep = 0; sweep < VG_BJ_MAXSWEEP; ++sweep) {
+        bool any_sweep = false;
+        for (int R = 0; R < nb - 1; ++R) {
+            int I = 0, Jb = 1;
+#ifdef VG_EIG_STAMP
+            BST(t0s);
+#endif
+            if (grp < npair) vg_pair(nb, R, grp, I, Jb);
+            // ---- gather S, U = I -----------------------------------------------------------------------------
+            if (grp < npair)
+                for (int e = lt; e < 1024; e += 256) {
+                    const int r = e >> 5, c = e & 31;
+                    const int gi = vg_bgidx(I, Jb, r), gj = vg_bgidx(I, Jb, c);
+                    S[r * VG_BJ_LD + c] = Gp[vg_sym(gi, gj)];
+                    U[r * VG_BJ_LD + c] = (r == c) ? 1.0 : 0.0;
+                }
+            if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+            vg_round_barrier<true>();
+#ifdef VG_EIG_STAMP
+            BST(t1s); tG += t1s - t0s; ++nout;
+#endif
+            // ---- inner rounds ----------------------------------------------------------------------------------
+            bool any_outer = false;
+            const int nin = (R == 0) ? 31 : 16;
+            for (int t = 0; t < nin; ++t) {
+                const int par = t & 1;
+#ifdef VG_EIG_STAMP
+                BST(t0s); ++nin_tot;
+#endif
+                if (grp < npair && lt < 16) {
+                    int p, q;
+                    if (R == 0) vg_pair(32, t, lt, p, q);
+                    else { p = lt; q = 16 + ((lt + t) & 15); }
+                    const double spp = S[p * VG_BJ_LD + p], sqq = S[q * VG_BJ_LD + q], spq = S[p * VG_BJ_LD + q];
+                    double c = 1.0, sn = 0.0;
+                    if (fabs(spq) > thr) {
+                        const double d = sqq - spp, o = 2.0 * spq;
+                        const double ad = fabs(d), ao = fabs(o);
+                        const double ib = vg_rcp(fmax(ad, ao));
+                        const double dn = ad * ib, on = ao * ib;
+                        const double h2 = dn * dn + on * on;
+                        double tt = on * vg_rcp(dn + h2 * vg_rsq(h2));
+                        if ((d >= 0.0) != (o >= 0.0)) tt = -tt;
+                        c = vg_rsq(1.0 + tt * tt);
+                        sn = tt * c;
+                        flags[par] = 1;
+                    }
+                    cs[grp * 16 + lt] = make_double2(c, sn);
+                    pq[grp * 16 + lt].p = p;
+                    pq[grp * 16 + lt].q = q;
+                }
+                if (tid == nthr - 1) flags[par ^ 1] = 0;
+#ifdef VG_EIG_STAMP
+                BST(t1s); tP += t1s - t0s;
+#endif
+                vg_round_barrier<true>();
+#ifdef VG_EIG_STAMP
+                BST(t0s); tB1 += t0s - t1s;
+#endif
+                if (!flags[par]) continue;                      // uniform: nobody rotates in this inner round
+                any_outer = true;
+                if (grp < npair) {
+                    // one 2x2 block of S (full storage, both triangles) and two 2-element column rotations of U per thread
+                    const int a = lt >> 4, b = lt & 15;
+                    const int pa = pq[grp * 16 + a].p, qa = pq[grp * 16 + a].q;
+                    const int pb = pq[grp * 16 + b].p, qb = pq[grp * 16 + b].q;
+                    const double2 ca = cs[grp * 16 + a], cb = cs[grp * 16 + b];
+                    const int a00 = pa * VG_BJ_LD + pb, a01 = pa * VG_BJ_LD + qb, a10 = qa * VG_BJ_LD + pb,
+                              a11 = qa * VG_BJ_LD + qb;
+                    const int u0p = a * VG_BJ_LD + pb, u0q = a * VG_BJ_LD + qb;           // rows a and a + 16 of U
+                    const int u1p = (a + 16) * VG_BJ_LD + pb, u1q = (a + 16) * VG_BJ_LD + qb;
+                    const double g00 = S[a00], g01 = S[a01], g10 = S[a10], g11 = S[a11];
+                    const double v0p = U[u0p], v0q = U[u0q], v1p = U[u1p], v1q = U[u1q];
+                    const double h00 = cb.x * g00 - cb.y * g01, h01 = cb.y * g00 + cb.x * g01;
+                    const double h10 = cb.x * g10 - cb.y * g11, h11 = cb.y * g10 + cb.x * g11;
+                    S[a00] = ca.x * h00 - ca.y * h10;
+                    S[a10] = ca.y * h00 + ca.x * h10;
+                    S[a01] = ca.x * h01 - ca.y * h11;
+                    S[a11] = ca.y * h01 + ca.x * h11;
+                    U[u0p] = cb.x * v0p - cb.y * v0q;
+                    U[u0q] = cb.y * v0p + cb.x * v0q;
+                    U[u1p] = cb.x * v1p - cb.y * v1q;
+                    U[u1q] = cb.y * v1p + cb.x * v1q;
+                }
+#ifdef VG_EIG_STAMP
+                BST(t1s); tU += t1s - t0s;
+#endif
+                vg_round_barrier<true>();
+#ifdef VG_EIG_STAMP
+                BST(t0s); tB2 += t0s - t1s;
+#endif
+            }
+#ifdef VG_EIG_STAMP
+            BST(t0s);
+#endif
+            if (!any_outer) continue;                           // uniform: this block pairing was already diagonal
+            any_sweep = true;
+            if (nlog >= cap_rounds) { status = VGGP_ENOCONV; break; }
+            // ---- hand-off: previous outer rounds' log stores are long done; drain, rendezvous, publish, then log ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            vg_round_barrier<true>();
+            if (tid == 0) {
+                __hip_atomic_store(&J.counters[3], nlog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&J.roundlog[nlog], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (grp < npair) {
+                double* dst = ulog + ((long)nlog * npair + grp) * 1024;
+                for (int e = lt; e < 1024; e += 256)
+                    __hip_atomic_store(dst + e, U[(e >> 5) * VG_BJ_LD + (e & 31)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++nlog;
+            // ---- off-diagonal super-blocks: X = U_a^T (G_ab U_b), one 32 x 16 strip per wave ---------------------
+            const int nunits = npair * (npair - 1);
+            vg_bd4 X0 = {0.0, 0.0, 0.0, 0.0}, X1 = {0.0, 0.0, 0.0, 0.0};
+            int Ia = 0, Ja = 0, Ib = 0, Jbb = 0, jb = 0;
+            if (wave < nunits) {
+                const int sbi = wave >> 1;
+                jb = wave & 1;
+                int al = 1;
+                while ((al * (al + 1)) / 2 <= sbi) ++al;
+                const int be = sbi - (al * (al - 1)) / 2;
+                vg_pair(nb, R, al, Ia, Ja);
+                vg_pair(nb, R, be, Ib, Jbb);
+                const double* Ua = slots + al * VG_BJ_SLOT + 32 * VG_BJ_LD;
+                const double* Ub = slots + be * VG_BJ_SLOT + 32 * VG_BJ_LD;
+                const int fi = lane & 15, fk = lane >> 4;
+                const int gi0 = vg_bgidx(Ia, Ja, fi), gi1 = vg_bgidx(Ia, Ja, 16 + fi);
+                vg_bd4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int k = kk * 4 + fk;
+                    const int gk = vg_bgidx(Ib, Jbb, k);
+                    const double bval = Ub[k * VG_BJ_LD + jb * 16 + fi];
+                    T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Gp[vg_sym(gi0, gk)], bval, T0, 0, 0, 0);
+                    T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Gp[vg_sym(gi1, gk)], bval, T1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k0 = kk * 4 + fk, k1 = 16 + kk * 4 + fk;
+                    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k0 * VG_BJ_LD + fi], T0[kk], X0, 0, 0, 0);
+                    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k0 * VG_BJ_LD + 16 + fi], T0[kk], X1, 0, 0, 0);
+                    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k1 * VG_BJ_LD + fi], T1[kk], X0, 0, 0, 0);
+                    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k1 * VG_BJ_LD + 16 + fi], T1[kk], X1, 0, 0, 0);
+                }
+            }
+            vg_round_barrier<true>();                            // every strip has read its G_ab before anyone writes
+            if (wave < nunits) {
+                const int fi = lane & 15, fk = lane >> 4;
+                const int gj = vg_bgidx(Ib, Jbb, jb * 16 + fi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Gp[vg_sym(vg_bgidx(Ia, Ja, fk + 4 * r), gj)] = X0[r];
+                    Gp[vg_sym(vg_bgidx(Ia, Ja, 16 + fk + 4 * r), gj)] = X1[r];
+                }
+            }
+            if (grp < npair)                                     // diagonal super-block = the rotated S itself
+                for (int e = lt; e < 1024; e += 256) {
+                    const int r = e >> 5, c = e & 31;
+                    const int gi = vg_bgidx(I, Jb, r), gj = vg_bgidx(I, Jb, c);
+                    if (gi >= gj) Gp[vg_tri(gi) + gj] = S[r * VG_BJ_LD + c];
+                }
+            vg_round_barrier<true>();
+#ifdef VG_EIG_STAMP
+            BST(t1s); tA += t1s - t0s;
+#endif
+        }
+        ++sweeps;
+        if (status || !any_sweep) break;
+        if (sweep == VG_BJ_MAXSWEEP - 1) status = VGGP_ENOCONV;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < m; i += nthr) J.lam[i] = Gp[vg_tri(i) + i];
+    if (tid == 0) {
+        J.counters[0] = nlog;
+        J.counters[1] = sweeps;
+        J.counters[2] = status;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef VG_EIG_STAMP
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(J.gwork) + wave * 8;
+        dbg[0] = tP; dbg[1] = tB1; dbg[2] = tU; dbg[3] = tB2; dbg[4] = tG; dbg[5] = tA; dbg[6] = nin_tot; dbg[7] = nout;
+    }
+#endif
+}
+
+// replay role for the block log: a 16-column tile of Q^T per workgroup; wave g applies pair g's U with MFMA
+__device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int* s_sync) {
+    const int m = J.m;
+    const int nb = 2 * ((m + 31) / 32), Mp = 16 * nb, npair = nb >> 1;
+    const int j0 = cblock * 16;
+    if (j0 >= Mp) return;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    double* T = dyn;                                            // [Mp][17]
+    double* Ubuf = T + Mp * 17 + (Mp & 1);                      // [npair][32][32]
+    const double* ulog = reinterpret_cast<const double*>(J.rotlog);
+    for (int idx = tid; idx < Mp * 16; idx += nthr) {
+        const int i = idx >> 4, jj = idx & 15, j = j0 + jj;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (J.Qt0 && i < m && j < m) v = J.Qt0[i * m + j];
+        T[i * 17 + jj] = v;
+    }
+    int consumed = 0;
+    for (;;) {
+        if (tid == 0) {
+            int pw, spins = 0;
+            for (;;) {
+                pw = __hip_atomic_load(&J.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((pw & VG_EIG_DONE) || (pw & (VG_EIG_DONE - 1)) > consumed) break;
+                if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_sync[0] = pw;
+        }
+        __syncthreads();
+        const int pw = s_sync[0];
+        if (pw & 0x20000000) break;
+        const bool done = (pw & VG_EIG_DONE) != 0;
+        const int published = pw & 0x1fffffff;
+        if (published > consumed) {
+            const double* src = ulog + (long)consumed * npair * 1024;
+            for (int idx = tid; idx < npair * 1024; idx += nthr)
+                Ubuf[idx] = __hip_atomic_load(src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) s_sync[1] = __hip_atomic_load(&J.roundlog[consumed], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int R = s_sync[1];
+            if (wave < npair) {
+                int I, Jb;
+                vg_pair(nb, R, wave, I, Jb);
+                const int fi = lane & 15, fk = lane >> 4;
+                const double* Ug = Ubuf + wave * 1024;
+                double b[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) b[kk] = T[vg_bgidx(I, Jb, kk * 4 + fk) * 17 + fi];
+                vg_bd4 A0 = {0.0, 0.0, 0.0, 0.0}, A1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int k = kk * 4 + fk;
+                    A0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ug[k * 32 + fi], b[kk], A0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ug[k * 32 + 16 + fi], b[kk], A1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T[vg_bgidx(I, Jb, fk + 4 * r) * 17 + fi] = A0[r];
+                    T[vg_bgidx(I, Jb, 16 + fk + 4 * r) * 17 + fi] = A1[r];
+                }
+            }
+            ++consumed;
+        }
+        __syncthreads();
+        if (done && consumed >= published) break;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < m * 16; idx += nthr) {
+        const int i = idx >> 4, j = j0 + (idx & 15);
+        if (j < m) J.Qt[i * m + j] = T[i * 17 + (idx & 15)];
+    }
+}
+
 // One launch, two roles: blockIdx.x == 0 is the Jacobi producer of matrix blockIdx.y, blockIdx.x >= 1 replay its
 // rotation log on column block blockIdx.x-1 of Q^T while the producer is still running (the replay is ~3x faster
 // per round, so it finishes a few microseconds after the producer).  At most 2*(1+8) workgroups: always co-resident.
@@ -427,15 +747,26 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     __shared__ int nact_s[2];
     __shared__ double red[16];
     const VgEigJob& J = a.job[blockIdx.y];
+    const bool block_mode = J.m <= VG_BJ_MAX_M;
     if (blockIdx.x == 0) {
-        if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red);
+        if (block_mode) vg_bjacobi_body(J, vg_eig_dyn, cs, pq, nact_s, red);
+        else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red);
         else vg_jacobi_body<false>(J, J.gwork, cs, pq, act, isact, nact_s, red);
     } else {
-        vg_replay_body(J, blockIdx.x - 1, a.rp_cols, vg_eig_dyn, nact_s);
+        if (block_mode) vg_breplay_body(J, blockIdx.x - 1, vg_eig_dyn, nact_s);
+        else vg_replay_body(J, blockIdx.x - 1, a.rp_cols, vg_eig_dyn, nact_s);
     }
 }
 
 static const int VG_EIG_LDS_MAX_M = 184;      // packed lower triangle: 184*185/2*8 B = 136 KB (+ ~19 KB static)
+
+size_t vg_eigh_log_bytes(int m) {
+    const size_t m2 = m + (m & 1);
+    size_t scalar = (size_t)VG_EIG_MAXSWEEP * (m2 - 1 > 0 ? m2 - 1 : 1) * (m2 / 2) * sizeof(double2);
+    if (m > VG_BJ_MAX_M) return scalar;
+    const size_t nb = 2 * ((m + 31) / 32), np = nb / 2;
+    return (size_t)VG_BJ_MAXSWEEP * (nb - 1) * np * 1024 * sizeof(double);
+}
 
 hipError_t vg_eigh_setup() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),
@@ -461,7 +792,12 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
         const int m2 = m + (m & 1);
         a.use_lds[j] = m <= VG_EIG_LDS_MAX_M;
         size_t need = a.use_lds[j] ? (size_t)m2 * (m2 + 1) / 2 * sizeof(double) : 0;
-        const size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
+        size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
+        if (m <= VG_BJ_MAX_M) {
+            const size_t nb = 2 * ((m + 31) / 32), Mp = 16 * nb, np = nb / 2;
+            need = (((Mp * (Mp + 1) / 2 + 1) & ~size_t(1)) + np * VG_BJ_SLOT) * sizeof(double);
+            rp = (Mp * 17 + 2 + np * 1024) * sizeof(double);
+        }
         if (rp > need) need = rp;
         if (need > lds) lds = need;
         if (m2 > maxm2) maxm2 = m2;
