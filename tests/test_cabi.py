@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
 def test_version_and_stage_names(lib):
     assert lib.vggp_version() == 100
     names = [lib.vggp_stage_name(i).decode() for i in range(14)]
-    assert len(set(names)) == 14 and "jacobi_eigh" in names
+    assert len(set(names)) == 14 and any(n.startswith("jacobi_eigh") for n in names)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -76,13 +76,14 @@ def test_cholesky_inverse(engine, m, kind, ell):
     assert np.abs(L @ Li - np.eye(m)).max() < 1e-9 * max(1.0, np.linalg.cond(Lr) * 1e-4)
 
 
+@pytest.mark.parametrize("block", [False, True], ids=["scalar", "block"])
 @pytest.mark.parametrize("m,kind", [(1, "matern12"), (9, "matern12"), (64, "rbf"), (128, "matern32"), (150, "matern12")])
-def test_eigh(engine, m, kind):
+def test_eigh(engine, m, kind, block):
     xx = np.linspace(0, 1, 4 * m + 3)
     f = Kr.Factor("points", kind, np.linspace(0, 1, m), xx)
     d = Kr.dim_prepare(f, 0.2, 1.0)
     G = d.B @ d.B.T
-    lam, Qt, sweeps = engine.eigh(torch.tensor(G, device=DEV))
+    lam, Qt, sweeps = engine.eigh(torch.tensor(G, device=DEV), block=block)
     lam, Qt = lam.cpu().numpy(), Qt.cpu().numpy()
     w = np.linalg.eigvalsh(G)
     assert np.abs(np.sort(lam) - w).max() < 1e-12 * w.max()
@@ -110,16 +111,17 @@ def test_sumsq(engine):
     assert abs(engine.sumsq(y) - float((y * y).sum())) < 1e-9 * float((y * y).sum())
 
 
+@pytest.mark.parametrize("block", [False, True], ids=["scalar", "block"])
 @pytest.mark.parametrize("m", [128, 130, 150])
-def test_eigh_bitwise_repeatable(engine, m):
+def test_eigh_bitwise_repeatable(engine, m, block):
     """Fixed reduction/rotation order: repeated solves are bit-identical (also exercises odd pair counts,
     two angle-phase waves, sparse rounds and the concurrent log hand-off to the replay workgroups)."""
     f = Kr.Factor("points", "matern12", np.linspace(0, 1, m), np.linspace(0, 1, 4 * m + 3))
     d = Kr.dim_prepare(f, 0.2, 1.0)
     G = torch.tensor(d.B @ d.B.T, device=DEV)
-    lam0, Qt0, _ = engine.eigh(G)
+    lam0, Qt0, _ = engine.eigh(G, block=block)
     for _ in range(4):
-        lam, Qt, _ = engine.eigh(G)
+        lam, Qt, _ = engine.eigh(G, block=block)
         assert torch.equal(lam, lam0) and torch.equal(Qt, Qt0)
     Gn, Q = G.cpu().numpy(), Qt0.cpu().numpy()
     assert np.linalg.norm(Q @ Gn @ Q.T - np.diag(lam0.cpu().numpy())) < 2e-13 * np.linalg.norm(Gn)

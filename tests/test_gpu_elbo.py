@@ -92,3 +92,20 @@ def test_split_partials_equal_step(engine):
     pay = engine.elbo_partials(Y, case[6])
     e2, g2, _ = engine.elbo_finish(pay, engine.sumsq(Y), case[6])
     assert e2 == elbo and np.array_equal(g2, grad)
+
+
+def test_block_jacobi_variant_matches(engine):
+    """VGGP_FLAG_BLOCK_JACOBI (block eigensolver with MFMA updates) gives the same step as the default."""
+    n, m = 96, 48
+    X, y, x1, x2 = D.gen_grid(n, n)
+    g = np.linspace(0, 1, m)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    theta = [0.2, 0.25, 1.0, 0.9, 0.01]
+    out = []
+    for blk in (False, True):
+        engine.plan("matern52", "points", g, x1, "matern52", "points", g, x2, warm_start=True, block_jacobi=blk)
+        yy = engine.sumsq(Y)
+        res = [engine.elbo_step(Y, yy, np.array(theta) * (1 + 0.01 * it)) for it in range(3)]
+        out.append(res[-1])
+    assert abs(out[0][0] - out[1][0]) <= 1e-10 * abs(out[0][0])
+    assert rel(out[1][1], out[0][1]) < 1e-8

@@ -12,6 +12,7 @@ VGGP_OK, VGGP_EINVAL, VGGP_ENOTPD, VGGP_EHIP, VGGP_ENOMEM, VGGP_ESTATE, VGGP_ENO
 KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 NSTAGE = 14
 FLAG_B0_F32_KDELTA = 1
+FLAG_BLOCK_JACOBI = 2
 BASIS = {"points": 0, "b0": 1, "one": 2}
 
 
@@ -54,7 +55,7 @@ SYMBOLS = {
     "vggp_posterior": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "vggp_factor_build": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _D, _I, _P, _P, _P, _P, _P]),
     "vggp_cholesky_inverse": (_I, [_P, _P, _I64, _P, _P, C.POINTER(_D), _P]),
-    "vggp_eigh": (_I, [_P, _P, _I64, _P, _P, C.POINTER(C.c_int32), _P]),
+    "vggp_eigh": (_I, [_P, _P, _I64, _P, _P, C.POINTER(C.c_int32), _I, _P]),
     "vggp_gemm": (_I, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "vggp_kron_solve": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "vggp_sumsq": (_I, [_P, _P, _I64, C.POINTER(_D), _P]),

@@ -417,7 +417,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
-                         d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m)};
+                         d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
+                         (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -771,7 +772,8 @@ extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, do
     return VGGP_OK;
 }
 
-extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, double* Qt, int32_t* sweeps_out, void* stream) {
+extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, double* Qt, int32_t* sweeps_out, int flags,
+                         void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(G && lam && Qt && m >= 1 && m <= 256, "vggp_eigh: bad argument (1 <= m <= 256)");
     VG_HIP(hipSetDevice(c->device));
@@ -792,7 +794,8 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     clr.n = 1;
     clr.ptr[0] = counters; clr.nwords[0] = 4;
     VG_HIP(vg_clear_launch(&clr, st));
-    VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds, (long)logb};
+    VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds, (long)logb,
+               (flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
     VG_HIP(vg_eigh_launch(&j, 1, st));
     int hc[4] = {0, 0, 0, 0};
     VG_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));

@@ -111,6 +111,7 @@ struct VgEigJob {
     int m;
     int max_rounds;
     long log_bytes;       // size of the rotlog buffer in bytes (vg_eigh_log_bytes(m))
+    int block;            // 1: block-Jacobi variant (m <= 128), 0: scalar cyclic Jacobi
 };
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);

@@ -432,11 +432,45 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
 //     Qt[IJ, cols] <- U^T Qt[IJ, cols] with MFMA on their 16-column tile.
 // Per outer sweep: 31 + 16 (nb - 2) = m-ish inner rounds, each ~4x cheaper than a full-matrix round, plus nb - 1 applies.
 typedef double vg_bd4 __attribute__((ext_vector_type(4)));
-#define VG_BJ_LD 33
-#define VG_BJ_SLOT (2 * 32 * VG_BJ_LD)          // doubles per pair slot: S then U
+#define VG_BJ_SLOT (2 * 32 * 32)                // doubles per pair slot: S then U
+// 32 x 32 tiles are stored with row stride 32 and the column XOR-swizzled by 16 on odd rows: a half-wave that touches
+// rows {r, r+1} x 16 columns (every S / U access pattern here) then hits 32 distinct 8-byte banks (stride 33 gave
+// bank = 2 (r + c) mod 64, i.e. up to 4-way conflicts).
+__device__ __forceinline__ int vg_sw(int r, int c) { return (r << 5) + (c ^ ((r & 1) << 4)); }
 #define VG_BJ_MAXSWEEP 30
 
 __device__ __forceinline__ int vg_bgidx(int I, int Jb, int l) { return ((l < 16) ? I : Jb) * 16 + (l & 15); }
+
+// local pairings of the 32 indices of a sub-problem.  full == true: circle method, round t in [0, 31);
+// full == false: cross pairs only (i in the first block, j in the second), round t in [0, 16)
+__device__ __forceinline__ void vg_bpair(bool full, int t, int k, int& p, int& q) {
+    if (full) vg_pair(32, t, k, p, q);
+    else { p = k; q = 16 + ((k + t) & 15); }
+}
+// inverse: which pair of round t holds local index x, and is x its p (pos 0) or its q (pos 1)
+__device__ __forceinline__ void vg_bpair_inv(bool full, int t, int x, int& k, int& pos) {
+    if (full) {
+        if (x == 31) { k = 0; pos = 1; return; }
+        int d = x - t; if (d < 0) d += 31;
+        if (d == 0) { k = 0; pos = 0; }
+        else if (d <= 15) { k = d; pos = 0; }
+        else { k = 31 - d; pos = 1; }
+    } else {
+        if (x < 16) { k = x; pos = 0; }
+        else { k = ((x - 16) - t) & 15; pos = 1; }
+    }
+}
+// rotation (c, s) annihilating spq, or identity below the threshold
+__device__ __forceinline__ double2 vg_angle(double spp, double sqq, double spq, double thr, bool& rot) {
+    rot = fabs(spq) > thr;
+    if (!rot) return make_double2(1.0, 0.0);
+    const double d = sqq - spp, o = 2.0 * spq;
+    const double h2 = d * d + o * o;
+    double tt = fabs(o) * vg_rcp(fabs(d) + h2 * vg_rsq(h2));
+    if ((d >= 0.0) != (o >= 0.0)) tt = -tt;
+    const double c = vg_rsq(1.0 + tt * tt);
+    return make_double2(c, tt * c);
+}
 
 __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgPairRec* pq, int* flags, double* red) {
     const int m = J.m;
@@ -446,7 +480,7 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
     double* Gp = dyn;                                            // packed lower triangle of the padded matrix
     double* slots = dyn + ((Mp * (Mp + 1) / 2 + 1) & ~1);
     double* S = slots + grp * VG_BJ_SLOT;
-    double* U = S + 32 * VG_BJ_LD;
+    double* U = S + 32 * 32;
 
     double ss = 0.0;
     for (int idx = tid; idx < Mp * Mp; idx += nthr) {
@@ -487,8 +521,8 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
                 for (int e = lt; e < 1024; e += 256) {
                     const int r = e >> 5, c = e & 31;
                     const int gi = vg_bgidx(I, Jb, r), gj = vg_bgidx(I, Jb, c);
-                    S[r * VG_BJ_LD + c] = Gp[vg_sym(gi, gj)];
-                    U[r * VG_BJ_LD + c] = (r == c) ? 1.0 : 0.0;
+                    S[vg_sw(r, c)] = Gp[vg_sym(gi, gj)];
+                    U[vg_sw(r, c)] = (r == c) ? 1.0 : 0.0;
                 }
             if (tid == 0) { flags[0] = 0; flags[1] = 0; }
             vg_round_barrier<true>();
@@ -496,57 +530,142 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
             BST(t1s); tG += t1s - t0s; ++nout;
 #endif
             // ---- inner rounds ----------------------------------------------------------------------------------
+            // Software pipeline: the angles of round t+1 are computed by 16 lanes per group WHILE round t is applied.
+            // Those lanes read the (still old) S together with everybody else before barrier 1, rotate the three
+            // elements they need in registers, and publish cs[t+1]; S itself is only written between barrier 1 and 2.
+            const bool full = (R == 0);
+            const int nin = full ? 31 : 16;
+            // angle lanes: 16 lanes of wave `grp` of group `grp` (waves 0, 5, 10, 15 sit on four different SIMDs)
+            const bool pl = grp < npair && (lt >> 6) == grp && (lt & 63) < 16;
+            const int kl = lt & 63;
+            if (pl) {                                                // prologue: angles of round 0 straight from S
+                int p, q;
+                vg_bpair(full, 0, kl, p, q);
+                bool rot;
+                cs[grp * 16 + kl] = vg_angle(S[vg_sw(p, p)], S[vg_sw(q, q)], S[vg_sw(p, q)], thr, rot);
+                if (rot) flags[0] = 1;
+            }
+            vg_round_barrier<true>();
             bool any_outer = false;
-            const int nin = (R == 0) ? 31 : 16;
+            if (!full) {
+                // ---- cross rounds (R >= 1): p_k = k, q_k = 16 + ((k + t) & 15): most addresses are loop invariant ----
+                const int a = lt >> 4, b = lt & 15;
+                const int swa = (a & 1) << 4;
+                const int rowa = a << 5;
+                const int a00 = rowa + (b ^ swa);                        // S[pa][pb] and U[a][pb]
+                // angle lane k: pair A = k (holds p' = k as its p), pair B = (k+1)&15 (holds q' as its q)
+                const int kB = (kl + 1) & 15;
+                const int swk = (kl & 1) << 4, swB = (kB & 1) << 4;
+                for (int t = 0; t < 16; ++t) {
+                    const int cur = t & 1, nxt = cur ^ 1;
+                    const bool active = flags[cur] != 0;                 // uniform
+                    const double2* csc = cs + cur * 64 + grp * 16;
+                    if (tid == nthr - 1) flags[nxt] = 0;
+                    int a01 = 0, a10 = 0, a11 = 0;
+                    double g00 = 0, g01 = 0, g10 = 0, g11 = 0, v0p = 0, v0q = 0, v1p = 0, v1q = 0;
+                    double2 ca = make_double2(1.0, 0.0), cb = ca;
+                    if (active && grp < npair) {
+                        const int qa = 16 + ((a + t) & 15), qb = 16 + ((b + t) & 15);
+                        const int swq = (qa & 1) << 4;
+                        a01 = rowa + (qb ^ swa);
+                        a10 = (qa << 5) + (b ^ swq);
+                        a11 = (qa << 5) + (qb ^ swq);
+                        ca = csc[a];
+                        cb = csc[b];
+                        g00 = S[a00]; g01 = S[a01]; g10 = S[a10]; g11 = S[a11];
+                        v0p = U[a00]; v0q = U[a01]; v1p = U[a00 + 512]; v1q = U[a01 + 512];
+                    }
+                    double b00 = 0, b01 = 0, b10 = 0, b11 = 0, ea = 0, eb = 0, ec = 0, fa = 0, fb = 0, fc = 0;
+                    double2 cA = make_double2(1.0, 0.0), cB = cA;
+                    const bool pnext = pl && (t + 1 < 16);
+                    if (pnext) {
+                        const int qA = 16 + ((kl + t) & 15), qB = 16 + ((kl + t + 1) & 15);       // qB = q' of the next pair
+                        const int swqA = (qA & 1) << 4, swqB = (qB & 1) << 4;
+                        if (active) { cA = csc[kl]; cB = csc[kB]; }
+                        b00 = S[(kl << 5) + (kB ^ swk)]; b01 = S[(kl << 5) + (qB ^ swk)];
+                        b10 = S[(qA << 5) + (kB ^ swqA)]; b11 = S[(qA << 5) + (qB ^ swqA)];
+                        ea = S[(kl << 5) + (kl ^ swk)]; eb = S[(kl << 5) + (qA ^ swk)]; ec = S[(qA << 5) + (qA ^ swqA)];
+                        fa = S[(kB << 5) + (kB ^ swB)]; fb = S[(kB << 5) + (qB ^ swB)]; fc = S[(qB << 5) + (qB ^ swqB)];
+                    }
+                    if (active) vg_round_barrier<true>();                // all loads done: S / U may now be overwritten
+                    if (active && grp < npair) {
+                        const double h00 = cb.x * g00 - cb.y * g01, h01 = cb.y * g00 + cb.x * g01;
+                        const double h10 = cb.x * g10 - cb.y * g11, h11 = cb.y * g10 + cb.x * g11;
+                        S[a00] = ca.x * h00 - ca.y * h10;
+                        S[a10] = ca.y * h00 + ca.x * h10;
+                        S[a01] = ca.x * h01 - ca.y * h11;
+                        S[a11] = ca.y * h01 + ca.x * h11;
+                        U[a00] = cb.x * v0p - cb.y * v0q;
+                        U[a01] = cb.y * v0p + cb.x * v0q;
+                        U[a00 + 512] = cb.x * v1p - cb.y * v1q;
+                        U[a01 + 512] = cb.y * v1p + cb.x * v1q;
+                    }
+                    if (pnext) {
+                        // p' is the p of pair A (column 0 of J_A = (c, -s)); q' is the q of pair B (column 1 = (s, c))
+                        const double uA0 = cA.x, uA1 = -cA.y, uB0 = cB.y, uB1 = cB.x;
+                        const double n_pq = uA0 * (b00 * uB0 + b01 * uB1) + uA1 * (b10 * uB0 + b11 * uB1);
+                        const double n_pp = uA0 * (ea * uA0 + eb * uA1) + uA1 * (eb * uA0 + ec * uA1);
+                        const double n_qq = uB0 * (fa * uB0 + fb * uB1) + uB1 * (fb * uB0 + fc * uB1);
+                        bool rot;
+                        cs[nxt * 64 + grp * 16 + kl] = vg_angle(n_pp, n_qq, n_pq, thr, rot);
+                        if (rot) flags[nxt] = 1;
+                    }
+                    vg_round_barrier<true>();
+                    any_outer |= active;
+                }
+            } else
             for (int t = 0; t < nin; ++t) {
-                const int par = t & 1;
+                const int cur = t & 1, nxt = cur ^ 1;
 #ifdef VG_EIG_STAMP
                 BST(t0s); ++nin_tot;
 #endif
-                if (grp < npair && lt < 16) {
-                    int p, q;
-                    if (R == 0) vg_pair(32, t, lt, p, q);
-                    else { p = lt; q = 16 + ((lt + t) & 15); }
-                    const double spp = S[p * VG_BJ_LD + p], sqq = S[q * VG_BJ_LD + q], spq = S[p * VG_BJ_LD + q];
-                    double c = 1.0, sn = 0.0;
-                    if (fabs(spq) > thr) {
-                        const double d = sqq - spp, o = 2.0 * spq;
-                        const double ad = fabs(d), ao = fabs(o);
-                        const double ib = vg_rcp(fmax(ad, ao));
-                        const double dn = ad * ib, on = ao * ib;
-                        const double h2 = dn * dn + on * on;
-                        double tt = on * vg_rcp(dn + h2 * vg_rsq(h2));
-                        if ((d >= 0.0) != (o >= 0.0)) tt = -tt;
-                        c = vg_rsq(1.0 + tt * tt);
-                        sn = tt * c;
-                        flags[par] = 1;
-                    }
-                    cs[grp * 16 + lt] = make_double2(c, sn);
-                    pq[grp * 16 + lt].p = p;
-                    pq[grp * 16 + lt].q = q;
+                const bool active = flags[cur] != 0;                 // uniform
+                const double2* csc = cs + cur * 64 + grp * 16;
+                if (tid == nthr - 1) flags[nxt] = 0;
+                // ---- phase L: every load of the round ----------------------------------------------------------
+                int a00 = 0, a01 = 0, a10 = 0, a11 = 0, u0p = 0, u0q = 0, u1p = 0, u1q = 0;
+                double g00 = 0, g01 = 0, g10 = 0, g11 = 0, v0p = 0, v0q = 0, v1p = 0, v1q = 0;
+                double2 ca = make_double2(1.0, 0.0), cb = ca;
+                if (active && grp < npair) {
+                    const int a = lt >> 4, b = lt & 15;
+                    int pa, qa, pb, qb;
+                    vg_bpair(full, t, a, pa, qa);
+                    vg_bpair(full, t, b, pb, qb);
+                    ca = csc[a];
+                    cb = csc[b];
+                    a00 = vg_sw(pa, pb); a01 = vg_sw(pa, qb); a10 = vg_sw(qa, pb); a11 = vg_sw(qa, qb);
+                    u0p = vg_sw(a, pb); u0q = vg_sw(a, qb);
+                    u1p = vg_sw(a + 16, pb); u1q = vg_sw(a + 16, qb);
+                    g00 = S[a00]; g01 = S[a01]; g10 = S[a10]; g11 = S[a11];
+                    v0p = U[u0p]; v0q = U[u0q]; v1p = U[u1p]; v1q = U[u1q];
                 }
-                if (tid == nthr - 1) flags[par ^ 1] = 0;
+                double n_pp = 0, n_qq = 0, n_pq = 0;                 // next pair's three elements (angle lanes)
+                double b00 = 0, b01 = 0, b10 = 0, b11 = 0, ea = 0, eb = 0, ec = 0, fa = 0, fb = 0, fc = 0;
+                double2 cA = make_double2(1.0, 0.0), cB = cA;
+                int ip = 0, iq = 0;
+                const bool pnext = pl && (t + 1 < nin);
+                if (pnext) {
+                    int pn, qn, kA, kB, pA, qA, pB, qB;
+                    vg_bpair(full, t + 1, kl, pn, qn);
+                    vg_bpair_inv(full, t, pn, kA, ip);
+                    vg_bpair_inv(full, t, qn, kB, iq);
+                    vg_bpair(full, t, kA, pA, qA);
+                    vg_bpair(full, t, kB, pB, qB);
+                    if (active) { cA = csc[kA]; cB = csc[kB]; }
+                    b00 = S[vg_sw(pA, pB)]; b01 = S[vg_sw(pA, qB)];
+                    b10 = S[vg_sw(qA, pB)]; b11 = S[vg_sw(qA, qB)];
+                    ea = S[vg_sw(pA, pA)]; eb = S[vg_sw(pA, qA)]; ec = S[vg_sw(qA, qA)];
+                    fa = S[vg_sw(pB, pB)]; fb = S[vg_sw(pB, qB)]; fc = S[vg_sw(qB, qB)];
+                }
 #ifdef VG_EIG_STAMP
                 BST(t1s); tP += t1s - t0s;
 #endif
-                vg_round_barrier<true>();
+                if (active) vg_round_barrier<true>();                // all loads done: S / U may now be overwritten
 #ifdef VG_EIG_STAMP
                 BST(t0s); tB1 += t0s - t1s;
 #endif
-                if (!flags[par]) continue;                      // uniform: nobody rotates in this inner round
-                any_outer = true;
-                if (grp < npair) {
-                    // one 2x2 block of S (full storage, both triangles) and two 2-element column rotations of U per thread
-                    const int a = lt >> 4, b = lt & 15;
-                    const int pa = pq[grp * 16 + a].p, qa = pq[grp * 16 + a].q;
-                    const int pb = pq[grp * 16 + b].p, qb = pq[grp * 16 + b].q;
-                    const double2 ca = cs[grp * 16 + a], cb = cs[grp * 16 + b];
-                    const int a00 = pa * VG_BJ_LD + pb, a01 = pa * VG_BJ_LD + qb, a10 = qa * VG_BJ_LD + pb,
-                              a11 = qa * VG_BJ_LD + qb;
-                    const int u0p = a * VG_BJ_LD + pb, u0q = a * VG_BJ_LD + qb;           // rows a and a + 16 of U
-                    const int u1p = (a + 16) * VG_BJ_LD + pb, u1q = (a + 16) * VG_BJ_LD + qb;
-                    const double g00 = S[a00], g01 = S[a01], g10 = S[a10], g11 = S[a11];
-                    const double v0p = U[u0p], v0q = U[u0q], v1p = U[u1p], v1q = U[u1q];
+                // ---- phase C: stores of round t, angles of round t+1 ------------------------------------------------
+                if (active && grp < npair) {
                     const double h00 = cb.x * g00 - cb.y * g01, h01 = cb.y * g00 + cb.x * g01;
                     const double h10 = cb.x * g10 - cb.y * g11, h11 = cb.y * g10 + cb.x * g11;
                     S[a00] = ca.x * h00 - ca.y * h10;
@@ -558,6 +677,17 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
                     U[u1p] = cb.x * v1p - cb.y * v1q;
                     U[u1q] = cb.y * v1p + cb.x * v1q;
                 }
+                if (pnext) {
+                    // column i of J = (c, -s) for i = 0, (s, c) for i = 1;  new[i][j] = u_i^T B v_j
+                    const double uA0 = ip ? cA.y : cA.x, uA1 = ip ? cA.x : -cA.y;
+                    const double uB0 = iq ? cB.y : cB.x, uB1 = iq ? cB.x : -cB.y;
+                    n_pq = uA0 * (b00 * uB0 + b01 * uB1) + uA1 * (b10 * uB0 + b11 * uB1);
+                    n_pp = uA0 * (ea * uA0 + eb * uA1) + uA1 * (eb * uA0 + ec * uA1);
+                    n_qq = uB0 * (fa * uB0 + fb * uB1) + uB1 * (fb * uB0 + fc * uB1);
+                    bool rot;
+                    cs[nxt * 64 + grp * 16 + kl] = vg_angle(n_pp, n_qq, n_pq, thr, rot);
+                    if (rot) flags[nxt] = 1;
+                }
 #ifdef VG_EIG_STAMP
                 BST(t1s); tU += t1s - t0s;
 #endif
@@ -565,6 +695,7 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
 #ifdef VG_EIG_STAMP
                 BST(t0s); tB2 += t0s - t1s;
 #endif
+                any_outer |= active;
             }
 #ifdef VG_EIG_STAMP
             BST(t0s);
@@ -582,7 +713,7 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
             if (grp < npair) {
                 double* dst = ulog + ((long)nlog * npair + grp) * 1024;
                 for (int e = lt; e < 1024; e += 256)
-                    __hip_atomic_store(dst + e, U[(e >> 5) * VG_BJ_LD + (e & 31)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + e, U[vg_sw(e >> 5, e & 31)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             ++nlog;
             // ---- off-diagonal super-blocks: X = U_a^T (G_ab U_b), one 32 x 16 strip per wave ---------------------
@@ -597,8 +728,8 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
                 const int be = sbi - (al * (al - 1)) / 2;
                 vg_pair(nb, R, al, Ia, Ja);
                 vg_pair(nb, R, be, Ib, Jbb);
-                const double* Ua = slots + al * VG_BJ_SLOT + 32 * VG_BJ_LD;
-                const double* Ub = slots + be * VG_BJ_SLOT + 32 * VG_BJ_LD;
+                const double* Ua = slots + al * VG_BJ_SLOT + 32 * 32;
+                const double* Ub = slots + be * VG_BJ_SLOT + 32 * 32;
                 const int fi = lane & 15, fk = lane >> 4;
                 const int gi0 = vg_bgidx(Ia, Ja, fi), gi1 = vg_bgidx(Ia, Ja, 16 + fi);
                 vg_bd4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
@@ -606,17 +737,17 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
                 for (int kk = 0; kk < 8; ++kk) {
                     const int k = kk * 4 + fk;
                     const int gk = vg_bgidx(Ib, Jbb, k);
-                    const double bval = Ub[k * VG_BJ_LD + jb * 16 + fi];
+                    const double bval = Ub[vg_sw(k, jb * 16 + fi)];
                     T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Gp[vg_sym(gi0, gk)], bval, T0, 0, 0, 0);
                     T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Gp[vg_sym(gi1, gk)], bval, T1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k0 = kk * 4 + fk, k1 = 16 + kk * 4 + fk;
-                    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k0 * VG_BJ_LD + fi], T0[kk], X0, 0, 0, 0);
-                    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k0 * VG_BJ_LD + 16 + fi], T0[kk], X1, 0, 0, 0);
-                    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k1 * VG_BJ_LD + fi], T1[kk], X0, 0, 0, 0);
-                    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[k1 * VG_BJ_LD + 16 + fi], T1[kk], X1, 0, 0, 0);
+                    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[vg_sw(k0, fi)], T0[kk], X0, 0, 0, 0);
+                    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[vg_sw(k0, 16 + fi)], T0[kk], X1, 0, 0, 0);
+                    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[vg_sw(k1, fi)], T1[kk], X0, 0, 0, 0);
+                    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ua[vg_sw(k1, 16 + fi)], T1[kk], X1, 0, 0, 0);
                 }
             }
             vg_round_barrier<true>();                            // every strip has read its G_ab before anyone writes
@@ -633,7 +764,7 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
                 for (int e = lt; e < 1024; e += 256) {
                     const int r = e >> 5, c = e & 31;
                     const int gi = vg_bgidx(I, Jb, r), gj = vg_bgidx(I, Jb, c);
-                    if (gi >= gj) Gp[vg_tri(gi) + gj] = S[r * VG_BJ_LD + c];
+                    if (gi >= gj) Gp[vg_tri(gi) + gj] = S[vg_sw(r, c)];
                 }
             vg_round_barrier<true>();
 #ifdef VG_EIG_STAMP
@@ -747,7 +878,7 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     __shared__ int nact_s[2];
     __shared__ double red[16];
     const VgEigJob& J = a.job[blockIdx.y];
-    const bool block_mode = J.m <= VG_BJ_MAX_M;
+    const bool block_mode = J.block && J.m <= VG_BJ_MAX_M;
     if (blockIdx.x == 0) {
         if (block_mode) vg_bjacobi_body(J, vg_eig_dyn, cs, pq, nact_s, red);
         else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red);
@@ -765,7 +896,8 @@ size_t vg_eigh_log_bytes(int m) {
     size_t scalar = (size_t)VG_EIG_MAXSWEEP * (m2 - 1 > 0 ? m2 - 1 : 1) * (m2 / 2) * sizeof(double2);
     if (m > VG_BJ_MAX_M) return scalar;
     const size_t nb = 2 * ((m + 31) / 32), np = nb / 2;
-    return (size_t)VG_BJ_MAXSWEEP * (nb - 1) * np * 1024 * sizeof(double);
+    const size_t blk = (size_t)VG_BJ_MAXSWEEP * (nb - 1) * np * 1024 * sizeof(double);
+    return blk > scalar ? blk : scalar;
 }
 
 hipError_t vg_eigh_setup() {
@@ -793,7 +925,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
         a.use_lds[j] = m <= VG_EIG_LDS_MAX_M;
         size_t need = a.use_lds[j] ? (size_t)m2 * (m2 + 1) / 2 * sizeof(double) : 0;
         size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
-        if (m <= VG_BJ_MAX_M) {
+        if (jobs[j].block && m <= VG_BJ_MAX_M) {
             const size_t nb = 2 * ((m + 31) / 32), Mp = 16 * nb, np = nb / 2;
             need = (((Mp * (Mp + 1) / 2 + 1) & ~size_t(1)) + np * VG_BJ_SLOT) * sizeof(double);
             rp = (Mp * 17 + 2 + np * 1024) * sizeof(double);

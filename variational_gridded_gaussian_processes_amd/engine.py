@@ -60,7 +60,8 @@ class Engine:
 
     # -- planning -------------------------------------------------------------------------------
     def plan(self, kind1: str, basis1: str, grid1, x1, kind2: str, basis2: str, grid2, x2,
-             n_total: Optional[int] = None, warm_start: bool = False, b0_f32_kdelta: bool = False) -> None:
+             n_total: Optional[int] = None, warm_start: bool = False, b0_f32_kdelta: bool = False,
+             block_jacobi: bool = False) -> None:
         """grid_d: mesh (m+1 knots, basis 'b0') or inducing coordinates (m, basis 'points');
         x_d: the n_d unique (local) observation coordinates along dimension d."""
         x1, x2 = _dvec(x1), _dvec(x2)
@@ -75,7 +76,7 @@ class Engine:
         d.x1, d.x2 = x1.ctypes.data, x2.ctypes.data
         d.grid1, d.grid2 = g1.ctypes.data, g2.ctypes.data
         d.warm_start = 1 if warm_start else 0
-        d.flags = _lib.FLAG_B0_F32_KDELTA if b0_f32_kdelta else 0
+        d.flags = (_lib.FLAG_B0_F32_KDELTA if b0_f32_kdelta else 0) | (_lib.FLAG_BLOCK_JACOBI if block_jacobi else 0)
         with torch.cuda.device(self.device):
             check(self.lib.vggp_plan(self._h, C.byref(d)))
         self.m1, self.m2, self.n1, self.n2 = m1, m2, len(x1), len(x2)
@@ -166,13 +167,14 @@ class Engine:
         check(self.lib.vggp_cholesky_inverse(self._h, _ptr(K), m, _ptr(L), _ptr(Li), C.byref(jit), _stream()))
         return L, Li, jit.value
 
-    def eigh(self, G: torch.Tensor):
+    def eigh(self, G: torch.Tensor, block: bool = False):
         """-> lam[m], Qt[m,m] (row j = eigenvector j), sweeps."""
         m = G.shape[0]
         lam = torch.empty(m, dtype=torch.float64, device=self.device)
         Qt = torch.empty_like(G)
         sw = C.c_int32()
-        check(self.lib.vggp_eigh(self._h, _ptr(G), m, _ptr(lam), _ptr(Qt), C.byref(sw), _stream()))
+        check(self.lib.vggp_eigh(self._h, _ptr(G), m, _ptr(lam), _ptr(Qt), C.byref(sw),
+                                 _lib.FLAG_BLOCK_JACOBI if block else 0, _stream()))
         return lam, Qt, sw.value
 
     def gemm(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
