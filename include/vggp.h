@@ -129,6 +129,18 @@ int vggp_elbo_partials(vggp_ctx* ctx, const double* Y, const double theta[5],
 int vggp_elbo_finish(vggp_ctx* ctx, const double* payload, double yy_total, const double theta[5],
                      double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 
+/* Masked / partially observed grid (BASELINE config 5).  Ym = W o Y and W (0/1 as float64) are DEVICE [n2][n1];
+ * n_obs = sum(W), yy_obs = sum(Ym^2).  Phi = Kuf W Kuf^T is assembled in M-space (M = m1 m2 <= 8192) and factored
+ * densely; value + analytic gradient as for vggp_elbo_step.  Replaces KroneckerStructure._elbo
+ * (kronecker_structure.py:249-278) called with the observed subset of the grid as X, y.  Single rank. */
+int vggp_elbo_step_masked(vggp_ctx* ctx, const double* Ym, const double* W, double n_obs, double yy_obs,
+                          const double theta[5], double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
+/* q(v) of the last masked step: mean and covariance diagonal, DEVICE [m1][m2]. */
+int vggp_qv_masked(vggp_ctx* ctx, double* mean, double* var, void* stream);
+/* posterior(x*) of the last masked step (kronecker_structure.py:199-230); arguments as vggp_posterior. */
+int vggp_posterior_masked(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t n_star, double* mean, double* var,
+                          void* stream);
+
 /* q(v) of the last finished step: mean and diagonal of the covariance, both DEVICE
  * [m1][m2] (flat index u = i1*m2+i2).  Replaces Matern12GriddedGP.q_v
  * (gridded_kronecker_structure.py:1409-1433 == kronecker_structure.py:825-849). */

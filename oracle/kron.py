@@ -325,3 +325,125 @@ def kron_solve(L1: np.ndarray, L2: np.ndarray, Y: np.ndarray) -> np.ndarray:
     """(K1 (x) K2)^{-1} vec(Y) matricised: Y is (n1, n2), K_d = L_d L_d^T."""
     T = sla.cho_solve((L1, True), Y)
     return sla.cho_solve((L2, True), T.T).T
+
+
+# ----------------------------------------------------------------------------
+# masked / partially observed grids (BASELINE config 5): Phi = Kuf W Kuf^T is no longer a Kronecker
+# product, so Sigma~ = I + rho Phi~0 is assembled in M-space (M = m1 m2) from the per-dimension factors
+# and factored densely.  Everything stays at unit outputscale; rho = s1 s2 / sigma^2.
+# ----------------------------------------------------------------------------
+@dataclass
+class MaskedState:
+    theta: np.ndarray
+    d1: DimState
+    d2: DimState
+    Sinv: np.ndarray          # Sigma~^{-1}  (M x M)
+    A0: np.ndarray            # mat(Sigma~^{-1} c~0)  (m1 x m2)
+    N: int
+    elbo: float = 0.0
+    grad: np.ndarray = field(default_factory=lambda: np.zeros(5))
+
+
+def _assemble(P1a, P1b, P2a, P2b, W):
+    """sum over observed (i, j) of (P1a[:,i] (x) P2a[:,j]) (P1b[:,i] (x) P2b[:,j])^T  -> (M x M).
+    W[j, i] in {0, 1}.  Done as T[i, (a,b)] = sum_j W[j,i] P2a[a,j] P2b[b,j]  (one GEMM), then
+    R[(i1,k1), (a,b)] = sum_i P1a[i1,i] P1b[k1,i] T[i,(a,b)]  (one GEMM), then a permutation."""
+    m1, n1 = P1a.shape
+    m2, n2 = P2a.shape
+    PP2 = (P2a[:, None, :] * P2b[None, :, :]).reshape(m2 * m2, n2)
+    T = W.T @ PP2.T                                        # (n1, m2^2)
+    PP1 = (P1a[:, None, :] * P1b[None, :, :]).reshape(m1 * m1, n1)
+    R = (PP1 @ T).reshape(m1, m1, m2, m2)                  # [i1, k1, i2, k2]
+    return R.transpose(0, 2, 1, 3).reshape(m1 * m2, m1 * m2)
+
+
+def elbo_step_masked(Y: np.ndarray, W: np.ndarray, f1: Factor, f2: Factor, theta) -> MaskedState:
+    """Collapsed ELBO (kronecker_structure.py:249-278) and its gradient when only the grid points with
+    W[j, i] = 1 are observed (the reference simply gets the scattered subset as X, y)."""
+    ell1, ell2, s1, s2, v = [float(t) for t in theta]
+    W = np.asarray(W, dtype=np.float64)
+    Ym = Y * W
+    N = int(W.sum())
+    yy = float((Ym * Ym).sum())
+    d1, d2 = dim_prepare(f1, ell1, 1.0), dim_prepare(f2, ell2, 1.0)      # unit outputscale
+    B1, V1, B2, V2 = d1.B, d1.V, d2.B, d2.V
+    m1, m2 = B1.shape[0], B2.shape[0]
+    M = m1 * m2
+    rho = s1 * s2 / v
+    Phi = _assemble(B1, B1, B2, B2, W)
+    Sig = np.eye(M) + rho * Phi
+    Lc = np.linalg.cholesky(Sig)
+    Sinv = sla.cho_solve((Lc, True), np.eye(M))
+    logdet = 2.0 * np.log(np.diag(Lc)).sum()
+    c0 = (B1 @ Ym.T @ B2.T).reshape(-1)
+    a0 = Sinv @ c0
+    q = float(c0 @ a0)
+    A0 = a0.reshape(m1, m2)
+    trPhi = float(np.trace(Phi))
+    elbo = (-0.5 * (N * math.log(2 * math.pi) + N * math.log(v) + logdet + yy / v - (s1 * s2 / v ** 2) * q)
+            - (N * s1 * s2 - s1 * s2 * trPhi) / (2 * v))
+    # --- outputscales and noise: closed forms through rho
+    trSP = (M - np.trace(Sinv)) / rho                        # tr(Sigma~^{-1} Phi~0)
+    aPa = (q - float(a0 @ a0)) / rho                         # a0^T Phi~0 a0
+    common = -0.5 * (rho * trSP - (s1 * s2 / v ** 2) * q + (s1 * s2 / v ** 2) * rho * aPa)
+    g_s1 = common / s1 - (N * s2 - s2 * trPhi) / (2 * v)
+    g_s2 = common / s2 - (N * s1 - s1 * trPhi) / (2 * v)
+    g_v = (-0.5 * (N / v - (rho / v) * trSP - yy / v ** 2 + 2 * s1 * s2 * q / v ** 3 - (s1 * s2 * rho / v ** 3) * aPa)
+           + (N * s1 * s2 - s1 * s2 * trPhi) / (2 * v ** 2))
+    # --- lengthscales
+    nb1, nb2 = (B1 * B1).sum(0), (B2 * B2).sum(0)             # ||b_i||^2
+    S4 = Sinv.reshape(m1, m2, m1, m2)
+
+    def ell_grad(dim):
+        if dim == 1:
+            Phip = _assemble(B1, V1, B2, B2, W)
+            Mk, m_other = d1.Mk, m2
+            PTS = np.einsum("ajbj->ab", S4)                               # partial trace of Sigma~^{-1} over index 2
+            C1 = (V1 @ Ym.T @ B2.T).reshape(-1)
+            quadMk = np.einsum("ik,ij,kj->", Mk, A0, A0)
+            Z = float((W * ((B2.T @ A0.T @ V1) * (B2.T @ A0.T @ B1))).sum())   # [j, i] layout
+            hv = (V1 * B1).sum(0)
+            tr1 = float(hv @ (W.T @ nb2))
+            PT = (B1 * (W.T @ nb2)[None, :]) @ B1.T
+        else:
+            Phip = _assemble(B1, B1, B2, V2, W)
+            Mk, m_other = d2.Mk, m1
+            PTS = np.einsum("iaib->ab", S4)
+            C1 = (B1 @ Ym.T @ V2.T).reshape(-1)
+            quadMk = np.einsum("ik,ji,jk->", Mk, A0, A0)
+            Z = float((W * ((V2.T @ A0.T @ B1) * (B2.T @ A0.T @ B1))).sum())
+            hv = (V2 * B2).sum(0)
+            tr1 = float(hv @ (W @ nb1))
+            PT = (B2 * (W @ nb1)[None, :]) @ B2.T
+        ld = float((Mk * PTS.T).sum()) - m_other * np.trace(Mk) + 2 * rho * float((Sinv * Phip).sum())
+        quad = 2 * float(a0 @ C1) - quadMk - 2 * rho * Z
+        return -0.5 * (ld - (s1 * s2 / v ** 2) * quad) + (s1 * s2 / (2 * v)) * (2 * tr1 - float((Mk * PT.T).sum()))
+
+    st = MaskedState(theta=np.asarray(theta, float), d1=d1, d2=d2, Sinv=Sinv, A0=A0, N=N)
+    st.elbo = float(elbo)
+    st.grad = np.array([ell_grad(1), ell_grad(2), g_s1, g_s2, g_v])
+    return st
+
+
+def q_v_masked(st: MaskedState):
+    """q(v) mean and covariance diagonal, (m1, m2): mu = Kuu Sigma^{-1} c / sigma^2, S = Kuu Sigma^{-1} Kuu."""
+    _, _, s1, s2, v = st.theta
+    L1, L2 = st.d1.L, st.d2.L                                  # unit-outputscale Cholesky factors
+    mean = (s1 * s2 / v) * (L1 @ st.A0 @ L2.T)
+    Lk = np.kron(L1, L2)
+    var = s1 * s2 * np.einsum("ab,bc,ac->a", Lk, st.Sinv, Lk)
+    return mean, var.reshape(mean.shape)
+
+
+def posterior_masked(st: MaskedState, f1: Factor, f2: Factor, x_star: np.ndarray):
+    """Point-wise posterior mean / variance at x_star (N*, 2) in masked mode (kronecker_structure.py:222-227 on the
+    observed subset): t = (L1^{-1} a1*) (x) (L2^{-1} a2*), mean = rho t^T a0, var = s1 s2 (1 - |t|^2 + t^T Sigma~^{-1} t)."""
+    ell1, ell2, s1, s2, v = st.theta
+    ts = []
+    for f, d, ell, col in ((f1, st.d1, ell1, 0), (f2, st.d2, ell2, 1)):
+        _, _, A0, _ = f.build(ell, x=np.asarray(x_star[:, col], float))
+        ts.append(sla.solve_triangular(d.L, A0, lower=True))
+    T = np.einsum("ip,jp->ijp", ts[0], ts[1]).reshape(-1, x_star.shape[0])
+    mean = (s1 * s2 / v) * (T.T @ st.A0.reshape(-1))
+    var = s1 * s2 * (1.0 - (T * T).sum(0) + np.einsum("up,uw,wp->p", T, st.Sinv, T))
+    return mean, var

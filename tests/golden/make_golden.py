@@ -57,6 +57,31 @@ def make_case(name, spec):
     print(name, float(elbo))
 
 
+MASK_CASES = {
+    # BASELINE.json configs[4]: missing observations under a mask (the reference receives only the observed subset)
+    "mask30_b0_m12_32x32": (32, 32, "b0", "matern12", ("lin", 0, 1, 9), ("lin", 0, 1, 9), [0.25, 0.2, 1.0, 1.2, 0.01], "f64", 0.3),
+    "mask30_pts_m32_24x20": (24, 20, "points", "matern32", ("lin", 0, 1, 10), ("lin", 0, 1, 8), [0.3, 0.25, 0.9, 1.2, 0.01], "f64", 0.3),
+}
+
+
+def make_mask_case(name, spec):
+    n1, n2, basis, kind, g1s, g2s, theta, mdt, frac = spec
+    X, y, x1, x2 = D.gen_grid(n1, n2, seed=len(name))
+    W = np.random.default_rng(5).uniform(size=(n2, n1)) > frac          # observed grid points
+    g1, g2 = grid(g1s, mdt), grid(g2s, mdt)
+    raw = D.raw_from_constrained(theta)
+    dm = D.DenseKron(X, y, basis, kind, g1, g2, raw=raw, mask=W.reshape(-1))
+    elbo, graw = dm.elbo_and_grad()
+    qv = dm.q_v()
+    np.savez(os.path.join(HERE, f"oracle_{name}.npz"),
+             X=X, y=y, x1=x1, x2=x2, W=W, grid1=g1.double().numpy(), grid2=g2.double().numpy(),
+             mesh_is_f32=np.array(False), basis=np.array(basis), kind=np.array(kind),
+             raw=raw.numpy(), theta=dm.theta().detach().numpy(), jitter=np.array(dm.jitters()),
+             elbo=elbo.numpy(), grad_raw=graw.numpy(),
+             qv_mean=qv.mean.detach().numpy(), qv_var=qv.variance.detach().numpy())
+    print(name, float(elbo))
+
+
 def make_1d():
     n, nknots = 256, 33
     x = np.linspace(0, 2 * np.pi, n)
@@ -98,5 +123,7 @@ def make_ref_pins():
 if __name__ == "__main__":
     for k, v in CASES.items():
         make_case(k, v)
+    for k, v in MASK_CASES.items():
+        make_mask_case(k, v)
     make_1d()
     make_ref_pins()

@@ -109,3 +109,55 @@ def test_block_jacobi_variant_matches(engine):
         out.append(res[-1])
     assert abs(out[0][0] - out[1][0]) <= 1e-10 * abs(out[0][0])
     assert rel(out[1][1], out[0][1]) < 1e-8
+
+
+MASK_CASES = [
+    (12, 10, "b0", "matern12", np.linspace(0, 1, 6), np.linspace(0, 1, 5), [0.2, 0.3, 1.1, 0.8, 0.02], 0.3),
+    (32, 32, "b0", "matern12", np.linspace(0, 1, 9), np.linspace(0, 1, 9), [0.25, 0.2, 1.0, 1.2, 0.01], 0.3),
+    (40, 36, "points", "matern32", np.linspace(0, 1, 12), np.linspace(0, 1, 13), [0.3, 0.25, 0.9, 1.2, 0.01], 0.3),
+    (24, 20, "points", "rbf", np.linspace(0, 1, 5), np.linspace(0, 1, 6), [0.3, 0.25, 0.9, 1.2, 0.01], 0.0),
+]
+
+
+@pytest.mark.parametrize("case", MASK_CASES, ids=lambda c: f"{c[2]}-{c[3]}-{c[0]}x{c[1]}-miss{c[7]}")
+def test_masked_step_vs_oracle(engine, case):
+    """BASELINE config 5 shape (missing observations under a mask): ELBO, gradient and q(v) against the structured
+    masked oracle (itself == dense restatement on the observed subset to 1e-14, tests/test_oracle.py)."""
+    n1, n2, basis, kind, g1, g2, theta, frac = case
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    Wn = (np.random.default_rng(1).uniform(size=(n2, n1)) > frac).astype(np.float64)
+    f1, f2 = Kr.Factor(basis, kind, np.asarray(g1, float), x1), Kr.Factor(basis, kind, np.asarray(g2, float), x2)
+    st = Kr.elbo_step_masked(y.reshape(n2, n1), Wn, f1, f2, theta)
+    engine.plan(kind, basis, g1, x1, kind, basis, g2, x2)
+    W = torch.tensor(Wn, device=DEV)
+    Ym = torch.tensor(y.reshape(n2, n1), device=DEV) * W
+    elbo, grad, info = engine.elbo_step_masked(Ym, W, float(Wn.sum()), engine.sumsq(Ym), theta)
+    assert info["status"] == 0
+    assert abs(elbo - st.elbo) <= RTOL * abs(st.elbo)
+    assert rel(grad, st.grad) < RTOL
+    mean, var = engine.qv_masked()
+    rm, rv = Kr.q_v_masked(st)
+    assert rel(mean.cpu().numpy(), rm) < RTOL and rel(var.cpu().numpy(), rv) < RTOL
+    xs = np.random.default_rng(9).uniform(0, 1, (3 * len(g1) * len(g2) + 5, 2))     # > M points: two chunks
+    pm, pv = engine.posterior_masked(torch.tensor(xs, device=DEV))
+    om, ov = Kr.posterior_masked(st, f1, f2, xs)
+    assert rel(pm.cpu().numpy(), om) < RTOL and rel(pv.cpu().numpy(), ov) < 1e-6
+    if frac == 0.0:      # full mask: the masked solver must agree with the Kronecker (eigen) path
+        e2, g2_, _ = engine.elbo_step(Ym, engine.sumsq(Ym), theta)
+        assert abs(e2 - elbo) <= 1e-9 * abs(elbo) and rel(grad, g2_) < 1e-7
+
+
+def test_masked_blocked_cholesky_multi_panel(engine):
+    """M = 18 x 17 = 306 > 128: exercises the blocked (3-panel) dense Cholesky / inverse."""
+    n1, n2 = 48, 40
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    Wn = (np.random.default_rng(3).uniform(size=(n2, n1)) > 0.3).astype(np.float64)
+    g1, g2 = np.linspace(0, 1, 18), np.linspace(0, 1, 17)
+    theta = [0.2, 0.25, 1.0, 1.1, 0.01]
+    f1, f2 = Kr.Factor("points", "matern32", g1, x1), Kr.Factor("points", "matern32", g2, x2)
+    st = Kr.elbo_step_masked(y.reshape(n2, n1), Wn, f1, f2, theta)
+    engine.plan("matern32", "points", g1, x1, "matern32", "points", g2, x2)
+    W = torch.tensor(Wn, device=DEV)
+    Ym = torch.tensor(y.reshape(n2, n1), device=DEV) * W
+    elbo, grad, info = engine.elbo_step_masked(Ym, W, float(Wn.sum()), engine.sumsq(Ym), theta)
+    assert abs(elbo - st.elbo) <= RTOL * abs(st.elbo) and rel(grad, st.grad) < RTOL

@@ -8,7 +8,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(glob.glob(os.path.join(GOLD, "oracle_*x*.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "oracle_*x*.npz")) if "mask" not in p)
+MASK_CASES = sorted(glob.glob(os.path.join(GOLD, "oracle_mask*.npz")))
 RTOL = 1e-7          # north-star tolerance is 1e-5; float64 end to end does far better
 
 
@@ -36,6 +37,24 @@ def test_engine_vs_golden(engine, path):
     pm, pv = engine.posterior(torch.tensor(g["xs"], device="cuda"))
     assert rel(pm.cpu().numpy(), g["post_mean"]) < RTOL
     assert rel(pv.cpu().numpy(), g["post_var"]) < 1e-6
+
+
+@pytest.mark.parametrize("path", MASK_CASES, ids=lambda p: os.path.basename(p)[7:-4])
+def test_engine_masked_vs_golden(engine, path):
+    """BASELINE config 5: golden = dense restatement run on the observed subset only."""
+    g = np.load(path)
+    basis, kind = str(g["basis"]), str(g["kind"])
+    n1, n2 = len(g["x1"]), len(g["x2"])
+    engine.plan(kind, basis, g["grid1"], g["x1"], kind, basis, g["grid2"], g["x2"])
+    W = torch.tensor(g["W"].astype(np.float64), device="cuda")
+    Ym = torch.tensor(g["y"].reshape(n2, n1), device="cuda") * W
+    elbo, grad, info = engine.elbo_step_masked(Ym, W, float(g["W"].sum()), engine.sumsq(Ym), g["theta"])
+    assert info["status"] == 0
+    assert abs(elbo - g["elbo"]) <= RTOL * abs(g["elbo"])
+    assert rel(grad / (1.0 + np.exp(-g["raw"])), g["grad_raw"]) < RTOL
+    mean, var = engine.qv_masked()
+    assert rel(mean.cpu().numpy().reshape(-1), g["qv_mean"]) < RTOL
+    assert rel(var.cpu().numpy().reshape(-1), g["qv_var"]) < RTOL
 
 
 def test_engine_vs_golden_1d(engine):

@@ -132,5 +132,39 @@ def test_initialisers_and_errors(engine):
     assert model.kernel_1.base_kernel.lengthscale.item() == ell_before       # the reference's getter quirk
     assert abs(model.likelihood.noise.item() - yt.var().item() / 100.0) < 1e-9
     assert np.isfinite(model._elbo().item())
-    with pytest.raises(ValueError):
-        Matern12GriddedGP(Xt[:-3], yt[:-3], 6, (0, 1), (0, 1), engine=engine)
+    with pytest.raises(ValueError):      # general scattered inputs (no underlying grid) are out of scope
+        Xr = torch.tensor(np.random.default_rng(0).uniform(size=(200, 2)))
+        Matern12GriddedGP(Xr, yt[:200] if len(yt) >= 200 else torch.zeros(200), 6, (0, 1), (0, 1), engine=engine)
+    with pytest.raises(ValueError):      # duplicated points
+        Matern12GriddedGP(torch.cat([Xt[:-3], Xt[:1]]), torch.cat([yt[:-3], yt[:1]]), 6, (0, 1), (0, 1), engine=engine)
+
+
+def test_masked_grid_model_matches_dense_oracle(engine):
+    """BASELINE config 5 through the model API: the reference gets the observed subset as X, y (any order)."""
+    from variational_gridded_gaussian_processes_amd.models import Matern12GriddedGP
+    n1, n2, nk = 32, 32, 9
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    rng = np.random.default_rng(4)
+    keep = rng.permutation(np.flatnonzero(rng.uniform(size=n1 * n2) > 0.3))      # 30% missing, shuffled order
+    Xo, yo = X[keep], y[keep]
+    model = Matern12GriddedGP(torch.tensor(Xo), torch.tensor(yo), nk, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    assert model._masked
+    dm = D.DenseKron(Xo, yo, "b0", "matern12", torch.linspace(0, 1, nk), torch.linspace(0, 1, nk))
+    e = model._elbo()
+    e.backward()
+    ed, gd = dm.elbo_and_grad()
+    assert abs(e.item() - ed.item()) <= 1e-5 * abs(ed.item())
+    got = np.array([model.kernel_1.base_kernel.raw_lengthscale.grad.item(),
+                    model.kernel_2.base_kernel.raw_lengthscale.grad.item(),
+                    model.kernel_1.raw_outputscale.grad.item(), model.kernel_2.raw_outputscale.grad.item(),
+                    model.likelihood.raw_noise.grad.item()])
+    assert rel(got, gd.numpy()) < 1e-5
+    qv, qd = model.q_v(), dm.q_v()
+    assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5
+    assert rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+    xs = rng.uniform(0, 1, (300, 2))
+    po, pd = model.posterior(torch.tensor(xs)), dm.posterior(xs)
+    assert rel(po.mean.numpy(), pd.mean.detach().numpy()) < 1e-5
+    assert rel(po.variance.numpy(), pd.variance.detach().numpy()) < 1e-5
+    hist = model.fit(n_iter=5, lr=0.05)            # the fit loop runs and improves the bound
+    assert hist[-1] < hist[0]

@@ -50,9 +50,12 @@ SYMBOLS = {
     "vggp_elbo_step": (_I, [_P, _P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
     "vggp_elbo_partials": (_I, [_P, _P, C.POINTER(_D), _P, _P]),
     "vggp_elbo_finish": (_I, [_P, _P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
+    "vggp_elbo_step_masked": (_I, [_P, _P, _P, _D, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
+    "vggp_qv_masked": (_I, [_P, _P, _P, _P]),
     "vggp_qv": (_I, [_P, _P, _P, _P]),
     "vggp_qv_cov": (_I, [_P, _P, _P]),
     "vggp_posterior": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
+    "vggp_posterior_masked": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "vggp_factor_build": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _D, _I, _P, _P, _P, _P, _P]),
     "vggp_cholesky_inverse": (_I, [_P, _P, _I64, _P, _P, C.POINTER(_D), _P]),
     "vggp_eigh": (_I, [_P, _P, _I64, _P, _P, C.POINTER(C.c_int32), _I, _P]),

@@ -24,71 +24,7 @@ void vg_set_error(const char* fmt, ...) {
 extern "C" const char* vggp_last_error(void) { return g_err; }
 extern "C" int vggp_version(void) { return VGGP_VERSION; }
 
-struct VgDim {
-    int kind = 0, basis = 0, n = 0, m = 0;
-    double *x = nullptr, *grid = nullptr;
-    double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
-    double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
-    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr;
-    double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
-    double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
-    double2* rotlog = nullptr;
-    int *roundlog = nullptr, *counters = nullptr, *status = nullptr;
-    int gh_split = 1, max_rounds = 0;
-    bool have_prev = false;
-};
-
-struct VgGraphKey {
-    const void* y = nullptr;
-    const void* payload = nullptr;
-    double yy = 0.0;
-    bool operator==(const VgGraphKey& o) const { return y == o.y && payload == o.payload && yy == o.yy; }
-};
-
-struct HostOut {            // pinned readback block
-    double out[8];
-    double jitter[2];
-    int counters[2][4];
-    int status[2];
-};
-
-struct vggp_ctx {
-    int device = 0;
-    bool planned = false;
-    vggp_desc desc{};
-    VgDim d[2];
-    void* arena = nullptr;
-    size_t arena_bytes = 0, arena_used = 0;
-    // cross-dimension buffers
-    double *St = nullptr, *CCslab = nullptr, *payload = nullptr, *GH1 = nullptr;
-    double *T3 = nullptr, *P3 = nullptr, *beta = nullptr, *bl2 = nullptr, *bl1 = nullptr, *invD = nullptr;
-    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
-    double *out = nullptr, *theta = nullptr, *wq = nullptr;
-    int st_split = 1, cc_split = 1;
-    long payload_len = 0;
-    bool have_partials = false, have_step = false;
-    // pinned host staging
-    double* h_theta = nullptr;
-    HostOut* h_out = nullptr;
-    // scratch for the exported building blocks / posterior (lazy)
-    void* misc = nullptr;
-    size_t misc_bytes = 0;
-    double* sumsq_partial = nullptr;
-    double* sumsq_out = nullptr;
-    // captured step graphs.  Capture is illegal on the legacy default stream, so when the caller passes stream 0 the
-    // step runs on `own_stream`, a BLOCKING stream: it is implicitly ordered with the legacy default stream in both
-    // directions (uploads / all-reduce issued by torch on stream 0 before, q(v) / posterior calls after).
-    hipStream_t own_stream = nullptr;
-    bool use_graph = true;
-    hipGraphExec_t gexec[5] = {};
-    VgGraphKey gkey[5];
-    // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
-    bool prof = false;
-    hipEvent_t ev[VGGP_NSTAGE + 2] = {};
-    bool ev_set[VGGP_NSTAGE + 2] = {};
-    double prof_ms[VGGP_NSTAGE] = {};
-    int prof_steps = 0;
-};
+#include "ctx.h"
 
 static void graphs_clear(vggp_ctx* c);
 
@@ -104,7 +40,7 @@ extern "C" const char* vggp_stage_name(int i) { return (i >= 0 && i < VGGP_NSTAG
         if (c->prof) { VG_HIP(hipEventRecord(c->ev[slot], st)); c->ev_set[slot] = true; } \
     } while (0)
 
-static int ensure_misc(vggp_ctx* c, size_t bytes) {
+int vg_ensure_misc(vggp_ctx* c, size_t bytes) {
     if (c->misc_bytes >= bytes) return VGGP_OK;
     if (c->misc) { VG_HIP(hipFree(c->misc)); c->misc = nullptr; c->misc_bytes = 0; }
     VG_HIP(hipMalloc(&c->misc, bytes));
@@ -144,6 +80,7 @@ extern "C" int vggp_destroy(vggp_ctx* c) {
     if (!c) return VGGP_OK;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < 5; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    vg_masked_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->arena) (void)hipFree(c->arena);
     if (c->misc) (void)hipFree(c->misc);
@@ -298,7 +235,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
         }
     }
     c->desc.x1 = c->desc.x2 = c->desc.grid1 = c->desc.grid2 = nullptr;   // host pointers not retained
-    c->have_partials = c->have_step = false;
+    c->have_partials = c->have_step = c->have_masked = false;
     c->planned = true;
     return VGGP_OK;
 }
@@ -309,7 +246,7 @@ extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t
 // ---------------------------------------------------------------------------------
 // Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
 // caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
-static int partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st) {
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st) {
     VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
@@ -560,7 +497,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     if (rc) return rc;
     if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
     const VgGraphKey key{Y, payload, 0.0};
-    rc = run_graph(c, VG_G_PARTIALS, key, st, [&] { return partials_enqueue(c, Y, payload, st); });
+    rc = run_graph(c, VG_G_PARTIALS, key, st, [&] { return vg_partials_enqueue(c, Y, payload, st); });
     if (rc) return rc;
     c->have_partials = true;
     return VGGP_OK;
@@ -594,7 +531,7 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{Y, c->payload, yy_total};
     rc = run_graph(c, warm ? VG_G_STEP_WARM : VG_G_STEP_COLD, key, st, [&] {
-        const int r1 = partials_enqueue(c, Y, c->payload, st);
+        const int r1 = vg_partials_enqueue(c, Y, c->payload, st);
         return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st);
     });
     if (rc) return rc;
@@ -662,7 +599,7 @@ extern "C" int vggp_qv_cov(vggp_ctx* c, double* cov, void* stream) {
     VG_REQUIRE(M <= 8192, "vggp_qv_cov: M=%ld too large for a dense covariance (use vggp_qv for mean/variance)", M);
     int rc = build_RQ(c, st);
     if (rc) return rc;
-    rc = ensure_misc(c, 2 * M * M * sizeof(double));
+    rc = vg_ensure_misc(c, 2 * M * M * sizeof(double));
     if (rc) return rc;
     double* Rk = (double*)c->misc;
     double* Rs = Rk + M * M;
@@ -689,7 +626,7 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
     if (ns == 0) return VGGP_OK;
     // per chunk: A(m x c), B(m x c), T(m x c) for both dims, T2sq, U, Uv (m1 x c)
     const size_t per = (size_t)chunk * (3 * m1 + 4 * m2 + 2 * m1);
-    int rc = ensure_misc(c, per * sizeof(double));
+    int rc = vg_ensure_misc(c, per * sizeof(double));
     if (rc) return rc;
     double* p = (double*)c->misc;
     double* A1 = p; p += m1 * chunk;
@@ -750,7 +687,7 @@ extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, do
     VG_REQUIRE(K && L && Linv && m >= 1 && m <= 1024, "vggp_cholesky_inverse: bad argument (1 <= m <= 1024)");
     VG_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    int rc = ensure_misc(c, (size_t)(m * (m + 1) + 16) * sizeof(double));
+    int rc = vg_ensure_misc(c, (size_t)(m * (m + 1) + 16) * sizeof(double));
     if (rc) return rc;
     double* scratch = (double*)c->misc;
     double* jit = scratch + m * (m + 1);
@@ -782,7 +719,7 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     const int max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
     const size_t logb = (vg_eigh_log_bytes((int)m) + 15) & ~size_t(15);
     const size_t need = (size_t)m2e * (m2e + 1) * 8 + logb + (size_t)max_rounds * 4 + 256;
-    int rc = ensure_misc(c, need);
+    int rc = vg_ensure_misc(c, need);
     if (rc) return rc;
     char* p = (char*)c->misc;
     double* gwork = (double*)p; p += (size_t)m2e * (m2e + 1) * 8;
@@ -824,7 +761,7 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, con
     VG_REQUIRE(L1inv && L2inv && Y && X && n1 >= 1 && n2 >= 1, "vggp_kron_solve: bad argument");
     VG_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    int rc = ensure_misc(c, 2 * (size_t)n1 * n2 * sizeof(double));
+    int rc = vg_ensure_misc(c, 2 * (size_t)n1 * n2 * sizeof(double));
     if (rc) return rc;
     double* T1 = (double*)c->misc;
     double* T2 = T1 + n1 * n2;

@@ -36,6 +36,7 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
     const int m = J.m;
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;      // 32 x 32 threads, each owns MT x MT elements
     const double jit = VG_JITTERS[lvl];
+    const int ldk = J.ldk ? J.ldk : m, ldl = J.ldl ? J.ldl : m;
     int* flags = reinterpret_cast<int*>(J.scratch);          // [4] per matrix, zeroed by the CALLER before the launch
 
     double a[MT][MT];
@@ -47,7 +48,7 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
 #pragma unroll
         for (int ib = 0; ib < MT; ++ib) {
             const int i = ty + 32 * ia, j = tx + 32 * ib;
-            a[ia][ib] = (i < m && j <= i) ? J.K[(long)i * m + j] + (i == j ? jit : 0.0) : 0.0;
+            a[ia][ib] = (i < m && j <= i) ? J.K[(long)i * ldk + j] + (i == j ? jit : 0.0) : 0.0;
         }
     }
 
@@ -119,7 +120,9 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
 
     // ---- level selection: the lowest successful level wins (relaxed agent-scope flags, no payload) ----------
     __syncthreads();
-    if (tid == 0) {
+    if (J.only_level0) {
+        if (tid == 0) { s_i[0] = ok ? 1 : 0; s_i[1] = ok ? 0 : 1; }
+    } else if (tid == 0) {
         __hip_atomic_store(&flags[lvl], ok ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int win = ok ? 1 : 0, spins = 0;
         bool all_failed = !ok;
@@ -139,7 +142,7 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
     if (report_fail) {
         if (tid == 0) { *J.status = VGGP_ENOTPD; if (J.jitter_out) *J.jitter_out = -1.0; }
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int idx = tid; idx < m * m; idx += blockDim.x) { J.L[idx] = qnan; J.Linv[idx] = qnan; }
+        for (int idx = tid; idx < m * m; idx += blockDim.x) { J.L[(long)(idx / m) * ldl + idx % m] = qnan; J.Linv[idx] = qnan; }
     }
     if (!winner) return;
     if (tid == 0 && J.jitter_out) *J.jitter_out = jit;
@@ -151,11 +154,11 @@ __device__ void vg_chol_fast(const VgCholJob& J, int lvl, double* W, double* rsd
         for (int k = tx; k <= i; k += 32) {
             const double v = W[vg_ctri(i) + k] * rsd[k];
             W[vg_ctri(i) + k] = v;
-            J.L[(long)i * m + k] = v;
+            J.L[(long)i * ldl + k] = v;
         }
     for (int i = ty; i < m; i += 32)
         for (int k = tx; k < m; k += 32)
-            if (k > i) J.L[(long)i * m + k] = 0.0;
+            if (k > i) J.L[(long)i * ldl + k] = 0.0;
     __syncthreads();
 
     // ---- inverse by forward elimination on the identity (registers hold X, lower triangular) --------------------
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(1024) void vg_chol_kernel(const VgCholArgs a) {
     __shared__ int s_i[2];
     const VgCholJob& J = a.job[blockIdx.y];
     const int lvl = blockIdx.x;
+    if (J.only_level0 && lvl > 0) return;
     if (a.fast[blockIdx.y]) {
         if (J.m <= 64) vg_chol_fast<2>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);
         else vg_chol_fast<4>(J, lvl, vg_chol_dyn, sd, rowbuf, s_i);

@@ -45,6 +45,8 @@ struct VgGemmP {
     int tiles_m, tiles_n;
     int tile_start;    // first linear block index of this problem
     int kchunk;        // K elements per split (multiple of VG_BK)
+    double alpha;      // C = (accum ? C : 0) + alpha * A B
+    int accum;
 };
 struct VgGemmBatch {
     int nprob;
@@ -57,7 +59,7 @@ void vg_gemm_init(VgGemmBatch* b);
 // append one problem; returns index.  ksplit slabs land at C + s*c_slab.
 int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const double* B, long sb_k,
                 long sb_n, double* C, int ldc, int M, int N, int K, int ksplit = 1, long c_slab = 0,
-                int b_nslab = 1, long b_slab = 0);
+                int b_nslab = 1, long b_slab = 0, double alpha = 1.0, int accum = 0);
 hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st);
 
 // segment reduction: out[i] = sum_s in[s*slab + i]
@@ -86,13 +88,15 @@ hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const doub
 
 // ---- Cholesky + explicit inverse (chol.hip) ------------------------------------
 struct VgCholJob {
-    const double* K;      // [m][m]
-    double* L;            // [m][m] lower, zero above
+    const double* K;      // [m][ldk] (ldk = 0 -> m)
+    double* L;            // [m][ldl] lower, zero above (ldl = 0 -> m)
     double* Linv;         // [m][m] lower, zero above
     double* scratch;      // [m][m+1] global work area (used when m does not fit LDS)
     double* jitter_out;   // device scalar
     int* status;          // device int (0 ok, VGGP_ENOTPD)
     int m;
+    int ldk = 0, ldl = 0; // row strides of K and L when they are sub-blocks of larger matrices
+    int only_level0 = 0;  // 1: factor as is (no jitter levels); used for the well-conditioned Sigma~ blocks
 };
 hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st);
 hipError_t vg_chol_setup();   // opt-in to large dynamic LDS

@@ -1,0 +1,75 @@
+// Context and per-dimension workspace of libvggp_hip.so (shared by api.hip and masked.hip).
+#pragma once
+#include "common.h"
+
+struct VgDim {
+    int kind = 0, basis = 0, n = 0, m = 0;
+    double *x = nullptr, *grid = nullptr;
+    double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
+    double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
+    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr;
+    double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
+    double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
+    double2* rotlog = nullptr;
+    int *roundlog = nullptr, *counters = nullptr, *status = nullptr;
+    int gh_split = 1, max_rounds = 0;
+    bool have_prev = false;
+};
+
+struct VgGraphKey {
+    const void* y = nullptr;
+    const void* payload = nullptr;
+    double yy = 0.0;
+    bool operator==(const VgGraphKey& o) const { return y == o.y && payload == o.payload && yy == o.yy; }
+};
+
+struct HostOut {            // pinned readback block
+    double out[8];
+    double jitter[2];
+    int counters[2][4];
+    int status[2];
+};
+
+struct vggp_ctx {
+    int device = 0;
+    bool planned = false;
+    vggp_desc desc{};
+    VgDim d[2];
+    void* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    // cross-dimension buffers
+    double *St = nullptr, *CCslab = nullptr, *payload = nullptr, *GH1 = nullptr;
+    double *T3 = nullptr, *P3 = nullptr, *beta = nullptr, *bl2 = nullptr, *bl1 = nullptr, *invD = nullptr;
+    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
+    double *out = nullptr, *theta = nullptr, *wq = nullptr;
+    int st_split = 1, cc_split = 1;
+    long payload_len = 0;
+    bool have_partials = false, have_step = false, have_masked = false;
+    void* masked = nullptr;          // VgMasked workspace (masked.hip), allocated on first use
+    // pinned host staging
+    double* h_theta = nullptr;
+    HostOut* h_out = nullptr;
+    // scratch for the exported building blocks / posterior (lazy)
+    void* misc = nullptr;
+    size_t misc_bytes = 0;
+    double* sumsq_partial = nullptr;
+    double* sumsq_out = nullptr;
+    // captured step graphs.  Capture is illegal on the legacy default stream, so when the caller passes stream 0 the
+    // step runs on `own_stream`, a BLOCKING stream: it is implicitly ordered with the legacy default stream in both
+    // directions (uploads / all-reduce issued by torch on stream 0 before, q(v) / posterior calls after).
+    hipStream_t own_stream = nullptr;
+    bool use_graph = true;
+    hipGraphExec_t gexec[5] = {};
+    VgGraphKey gkey[5];
+    // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
+    bool prof = false;
+    hipEvent_t ev[VGGP_NSTAGE + 2] = {};
+    bool ev_set[VGGP_NSTAGE + 2] = {};
+    double prof_ms[VGGP_NSTAGE] = {};
+    int prof_steps = 0;
+};
+
+
+int vg_ensure_misc(vggp_ctx* c, size_t bytes);
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st);
+void vg_masked_free(vggp_ctx* c);

@@ -130,7 +130,11 @@ __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + wr * 32 + mb * 16 + fk + 4 * r;
                 const int col = col0 + wc * 32 + nb * 16 + fi;
-                if (row < M && col < N) C[(long)row * ldc + col] = acc[mb][nb][r];
+                if (row < M && col < N) {
+                    double* cp = C + (long)row * ldc + col;
+                    const double v = p.alpha * acc[mb][nb][r];
+                    *cp = p.accum ? *cp + v : v;
+                }
             }
 }
 
@@ -141,12 +145,13 @@ void vg_gemm_init(VgGemmBatch* b) {
 
 int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const double* B, long sb_k,
                 long sb_n, double* C, int ldc, int M, int N, int K, int ksplit, long c_slab,
-                int b_nslab, long b_slab) {
+                int b_nslab, long b_slab, double alpha, int accum) {
     if (b->nprob >= VG_GEMM_MAXP) return -1;
     VgGemmP& p = b->p[b->nprob];
     p.A = A; p.B = B; p.C = C;
     p.sa_m = sa_m; p.sa_k = sa_k; p.sb_k = sb_k; p.sb_n = sb_n;
     p.M = M; p.N = N; p.K = K; p.ldc = ldc;
+    p.alpha = alpha; p.accum = accum;
     if (ksplit < 1) ksplit = 1;
     int ktiles = (K + VG_BK - 1) / VG_BK;
     if (ktiles < 1) ktiles = 1;

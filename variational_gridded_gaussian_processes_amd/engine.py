@@ -103,6 +103,24 @@ class Engine:
                                       _stream()))
         return elbo.value, np.array(list(grad)), self._info(info)
 
+    def elbo_step_masked(self, Ym: torch.Tensor, W: torch.Tensor, n_obs: float, yy_obs: float, theta: Sequence[float]):
+        """Masked grid: Ym = W*Y and W (0/1 float64) are [n2, n1]; -> (elbo, grad[5], info)."""
+        self._check_Y(Ym)
+        self._check_Y(W)
+        th = (C.c_double * 5)(*[float(t) for t in theta])
+        elbo = C.c_double()
+        grad = (C.c_double * 5)()
+        info = Info()
+        check(self.lib.vggp_elbo_step_masked(self._h, _ptr(Ym), _ptr(W), float(n_obs), float(yy_obs), th, C.byref(elbo),
+                                             grad, C.byref(info), _stream()))
+        return elbo.value, np.array(list(grad)), self._info(info)
+
+    def qv_masked(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        mean = torch.empty(self.m1, self.m2, dtype=torch.float64, device=self.device)
+        var = torch.empty_like(mean)
+        check(self.lib.vggp_qv_masked(self._h, _ptr(mean), _ptr(var), _stream()))
+        return mean, var
+
     def elbo_partials(self, Y: torch.Tensor, theta: Sequence[float], payload: Optional[torch.Tensor] = None):
         self._check_Y(Y)
         if payload is None:
@@ -137,7 +155,11 @@ class Engine:
         check(self.lib.vggp_qv_cov(self._h, _ptr(cov), _stream()))
         return cov
 
-    def posterior(self, x_star: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def posterior_masked(self, x_star: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """posterior(x*) of the last masked step; x_star [ns, 2] -> mean[ns], var[ns]."""
+        return self.posterior(x_star, _fn="vggp_posterior_masked")
+
+    def posterior(self, x_star: torch.Tensor, _fn: str = "vggp_posterior") -> Tuple[torch.Tensor, torch.Tensor]:
         """x_star [ns, 2] (or [ns] with a trivial second dimension) -> mean[ns], var[ns]."""
         xs = x_star.to(self.device, torch.float64)
         if xs.dim() == 1:
@@ -146,7 +168,7 @@ class Engine:
         ns = xs1.shape[0]
         mean = torch.empty(ns, dtype=torch.float64, device=self.device)
         var = torch.empty_like(mean)
-        check(self.lib.vggp_posterior(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(mean), _ptr(var), _stream()))
+        check(getattr(self.lib, _fn)(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(mean), _ptr(var), _stream()))
         return mean, var
 
     # -- building blocks ------------------------------------------------------------------------------

@@ -140,24 +140,34 @@ class _ElboFunction(torch.autograd.Function):
         return grad_out * g, None
 
 
-def _detect_grid(X: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
-    """X (N,2) in gen_2d layout (utils/datagenerators.py:70-72: x1 fastest) -> unique (x1, x2)."""
+def _detect_grid(X: torch.Tensor):
+    """X (N,2) -> (x1, x2, W, flat).  Full grid in gen_2d layout (utils/datagenerators.py:70-72: x1 fastest): W and flat
+    are None.  Otherwise X must be a subset of the cartesian grid of its own unique coordinates (a masked grid,
+    BASELINE config 5): W[j, i] = 1 on observed points and flat[k] = j*n1 + i places y[k] on the grid."""
     Xn = X.detach().cpu().numpy().astype(np.float64)
     if Xn.ndim != 2 or Xn.shape[1] != 2:
         raise ValueError("X must be (N, 2)")
     N = Xn.shape[0]
     x2_first = Xn[0, 1]
     n1 = int(np.argmax(Xn[:, 1] != x2_first)) if np.any(Xn[:, 1] != x2_first) else N
-    if n1 == 0 or N % n1 != 0:
-        raise ValueError("X is not a full grid in gen_2d layout (x1 fastest)")
-    n2 = N // n1
-    G = Xn.reshape(n2, n1, 2)
-    x1, x2 = G[0, :, 0].copy(), G[:, 0, 1].copy()
-    if not (np.array_equal(G[:, :, 0], np.broadcast_to(x1, (n2, n1)))
-            and np.array_equal(G[:, :, 1], np.broadcast_to(x2[:, None], (n2, n1)))):
-        raise ValueError("X is not a full grid in gen_2d layout (x1 fastest); scattered/masked "
-                         "observations are not supported by this build yet")
-    return x1, x2
+    if n1 > 0 and N % n1 == 0:
+        n2 = N // n1
+        G = Xn.reshape(n2, n1, 2)
+        x1, x2 = G[0, :, 0].copy(), G[:, 0, 1].copy()
+        if (np.array_equal(G[:, :, 0], np.broadcast_to(x1, (n2, n1)))
+                and np.array_equal(G[:, :, 1], np.broadcast_to(x2[:, None], (n2, n1)))):
+            return x1, x2, None, None
+    x1, i = np.unique(Xn[:, 0], return_inverse=True)
+    x2, j = np.unique(Xn[:, 1], return_inverse=True)
+    if len(x1) * len(x2) > 16 * N:
+        raise ValueError("X is neither a full grid (gen_2d layout) nor a masked grid: its unique coordinates span "
+                         f"{len(x1)} x {len(x2)} grid points for {N} observations (general scattered inputs are out of scope)")
+    flat = j.astype(np.int64) * len(x1) + i.astype(np.int64)
+    W = np.zeros(len(x1) * len(x2))
+    W[flat] = 1.0
+    if int(W.sum()) != N:
+        raise ValueError("X holds duplicated points")
+    return x1, x2, W.reshape(len(x2), len(x1)), flat
 
 
 class KroneckerStructure(torch.nn.Module):
@@ -176,9 +186,18 @@ class KroneckerStructure(torch.nn.Module):
         self._warm = warm_start
         self._planned = False
         self.last_info = None
-        self._x1, self._x2 = _detect_grid(X)
+        self._x1, self._x2, W, flat = _detect_grid(X)
         n2, n1 = len(self._x2), len(self._x1)
-        self._Y = torch.as_tensor(y, dtype=torch.float64).reshape(n2, n1).contiguous().to(self._engine.device)
+        yd = torch.as_tensor(y, dtype=torch.float64).reshape(-1).to(self._engine.device)
+        self._masked = W is not None
+        if self._masked:                 # masked grid: scatter the observations onto the grid (zeros elsewhere)
+            self._W = torch.as_tensor(W, device=self._engine.device)
+            self._Y = torch.zeros(n2 * n1, dtype=torch.float64, device=self._engine.device)
+            self._Y[torch.as_tensor(flat, device=self._engine.device)] = yd
+            self._Y = self._Y.reshape(n2, n1)
+            self._nobs = float(W.sum())
+        else:
+            self._Y = yd.reshape(n2, n1).contiguous()
         self._yy = self._engine.sumsq(self._Y)
 
     # subclasses provide (basis, grid_1, grid_2)
@@ -205,6 +224,8 @@ class KroneckerStructure(torch.nn.Module):
 
     def _engine_step(self, theta):
         self._plan()
+        if self._masked:
+            return self._engine.elbo_step_masked(self._Y, self._W, self._nobs, self._yy, theta)
         return self._engine.elbo_step(self._Y, self._yy, theta)
 
     # -- reference API ---------------------------------------------------------------------------
@@ -221,6 +242,9 @@ class KroneckerStructure(torch.nn.Module):
         """gridded_kronecker_structure.py:1409-1433 == kronecker_structure.py:825-849.
         mean is flat (M,) with u = i1*m2 + i2 (callers do `.mean.reshape(m, m).T`)."""
         self._refresh()
+        if self._masked:
+            mean, var = self._engine.qv_masked()
+            return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
         mean, var = self._engine.qv()
         return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu(),
                                   cov_fn=lambda: self._engine.qv_cov().cpu())
@@ -228,7 +252,8 @@ class KroneckerStructure(torch.nn.Module):
     def posterior(self, x_star: torch.Tensor) -> MultivariateNormal:
         """kronecker_structure.py:199-230: mean and the diagonal of the covariance at x_star (N*, 2)."""
         self._refresh()
-        mean, var = self._engine.posterior(torch.as_tensor(x_star, dtype=torch.float64))
+        post = self._engine.posterior_masked if self._masked else self._engine.posterior
+        mean, var = post(torch.as_tensor(x_star, dtype=torch.float64))
         return MultivariateNormal(mean.cpu(), var.cpu())
 
     def posterior_predictive(self, x_star: torch.Tensor) -> MultivariateNormal:
@@ -337,6 +362,7 @@ class _SparseGP1D(torch.nn.Module):
         self._engine = engine if engine is not None else Engine()
         self._warm = warm_start
         self._planned = False
+        self._masked = False
         self.last_info = None
         self._x = torch.as_tensor(X, dtype=torch.float64).reshape(-1).numpy().copy()
         self._Y = torch.as_tensor(y, dtype=torch.float64).reshape(1, -1).contiguous().to(self._engine.device)
@@ -361,6 +387,8 @@ class _SparseGP1D(torch.nn.Module):
 
     def _engine_step(self, theta):
         self._plan()
+        if self._masked:
+            return self._engine.elbo_step_masked(self._Y, self._W, self._nobs, self._yy, theta)
         return self._engine.elbo_step(self._Y, self._yy, theta)
 
     def _elbo(self):
@@ -374,6 +402,9 @@ class _SparseGP1D(torch.nn.Module):
     def q_v(self) -> MultivariateNormal:
         """univariate_structure.py:693-717."""
         self._refresh()
+        if self._masked:
+            mean, var = self._engine.qv_masked()
+            return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
         mean, var = self._engine.qv()
         return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu(),
                                   cov_fn=lambda: self._engine.qv_cov().cpu())
