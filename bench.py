@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--kind", default="rbf")
     ap.add_argument("--cold", action="store_true", help="disable the eigensolver warm start")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of N>1 ranks "
+                                                      "sharing one GPU; never a reported number)")
     args = ap.parse_args()
 
     import torch
@@ -125,8 +127,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -153,15 +160,14 @@ def main():
     raw0[4] -= 1e-4
     raw0 = inv_softplus(raw0)
     opt = Adam(raw0, lr=0.01)
-    payload = torch.empty(eng.payload_len, dtype=torch.float64, device=eng.device)
+    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep
+    sharded = ShardedStep(eng) if world > 1 else None     # partials -> ONE all-reduce (RCCL) -> finish, on one stream
 
     def one_step():
         raw = opt.x
         th = theta_from_raw(raw.copy())
         if world > 1:
-            eng.elbo_partials(Y, th, payload)
-            dist.all_reduce(payload)
-            elbo, g, info = eng.elbo_finish(payload, yy, th)
+            elbo, g, info = sharded.step(Y, yy, th)
         else:
             elbo, g, info = eng.elbo_step(Y, yy, th)
         graw = g / (1.0 + np.exp(-raw))              # softplus chain rule

@@ -1,0 +1,77 @@
+"""2 ranks on ONE GPU (gloo carries the collective; on the 8-GPU node bench.py uses RCCL): the product seam
+vggp_elbo_partials -> all_reduce -> vggp_elbo_finish through ShardedStep equals the single-rank step and the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N1, N2, M1, M2 = 96, 70, 12, 9            # 70 rows over 2 ranks: 35 + 35; over 3 (shard_rows): 24 + 24 + 22
+THETA = [0.2, 0.3, 1.0, 0.8, 0.01]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import dense as D
+    from variational_gridded_gaussian_processes_amd import Engine
+    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, x1, x2 = D.gen_grid(N1, N2)
+        rows = shard_rows(N2, rank, world)
+        eng = Engine(0)
+        eng.plan("matern32", "points", np.linspace(0, 1, M1), x1, "matern32", "points", np.linspace(0, 1, M2), x2[rows],
+                 n_total=N1 * N2, warm_start=True)
+        Y = torch.tensor(y.reshape(N2, N1)[rows], device="cuda:0")
+        sh = ShardedStep(eng)
+        yy = sh.sumsq_total(Y)
+        out = []
+        for k in range(3):                       # cold step, then warm-started steps with moving hyper-parameters
+            th = np.array(THETA) * (1.0 + 0.05 * k)
+            e, g, info = sh.step(Y, yy, th)
+            out.append((e, g))
+        mean, var = eng.qv()
+        q.put((rank, out, mean.cpu().numpy(), var.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_equals_single_rank_and_oracle(engine, world):
+    from oracle import dense as D, kron as Kr
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    X, y, x1, x2 = D.gen_grid(N1, N2)
+    g1, g2 = np.linspace(0, 1, M1), np.linspace(0, 1, M2)
+    f1, f2 = Kr.Factor("points", "matern32", g1, x1), Kr.Factor("points", "matern32", g2, x2)
+    engine.plan("matern32", "points", g1, x1, "matern32", "points", g2, x2, warm_start=True)
+    Y = torch.tensor(y.reshape(N2, N1), device="cuda")
+    for k in range(3):
+        th = np.array(THETA) * (1.0 + 0.05 * k)
+        ref = Kr.elbo_step(y.reshape(N2, N1), f1, f2, th)
+        e1, g1_, _ = engine.elbo_step(Y, engine.sumsq(Y), th)
+        for rank, out, _, _ in res:
+            e, g = out[k]
+            assert abs(e - ref.elbo) <= 1e-9 * abs(ref.elbo)
+            assert np.abs(g - ref.grad).max() <= 1e-7 * np.abs(ref.grad).max()
+            assert abs(e - e1) <= 1e-10 * abs(e1)
+        assert all(r[1][k][0] == res[0][1][k][0] for r in res)         # every rank holds the identical value
+    rm, rv = Kr.q_v(ref)
+    for _, _, mean, var in res:
+        assert np.abs(mean - rm).max() <= 1e-7 * np.abs(rm).max()
+        assert np.abs(var - rv).max() <= 1e-7 * np.abs(rv).max()
