@@ -14,6 +14,8 @@
 //   of columns of Q^T; every wave owns its columns outright, so there is no barrier per round.
 #include "common.h"
 
+#include <cstdlib>
+
 #define VG_EIG_TOL 1e-13
 #ifndef VG_BJ_MAX_M
 #define VG_BJ_MAX_M 128            // block Jacobi up to this size, scalar cyclic Jacobi beyond
@@ -30,6 +32,7 @@ struct VgEigArgs {
     VgEigJob job[2];
     int njobs;
     int use_lds[2];
+    int fast[2];       // dense sweeps with fixed addresses (two copies of G fit LDS)
     int rp_cols;       // replay columns per workgroup (4 per working wave)
 };
 
@@ -101,9 +104,199 @@ __device__ __forceinline__ void vg_round_barrier() {
     }
 }
 
+
+// =====================================================================================================================
+// Dense sweeps with FIXED addresses (m2 <= 128, two packed copies of G in LDS).
+// vg_pair() is the circle method: player x sits at relative position u = (x - r) mod n1 in round r (n1 = m2 - 1, the
+// last player never moves) and pair k is always (position k, position n1 - k).  If the matrix is stored BY POSITION
+// and physically shifted by one position per round, every 2x2 block (al, be) = rows {al, n1-al} x cols {be, n1-be}
+// lives at the same addresses in every round, and so do its destinations (rows/cols shifted by -1, wrapped).  So:
+//   * a thread owns the same <= 2 off-diagonal blocks for the whole solve; their 4 read and 4 write addresses are
+//     computed once (the moving-index variant below spends more VALU issue on addresses than on the rotations);
+//   * reads come from one copy, writes go to the other (ping-pong): ONE barrier per round;
+//   * the diagonal is carried in closed form (d_p -= t g_pq, d_q += t g_pq, g_pq <- 0), so there is no angle phase:
+//     the off-diagonal element of a pair of the NEXT round is always an output of one fixed block of THIS round; those
+//     `half` blocks sit in wave 0, whose lanes compute the next rotations right after their block update while the other
+//     15 waves are still moving data.
+// The rotation sequence is the one of the moving-index variant (same pairs, same order), so the replay workgroups and
+// the log format are unchanged.  A round costs a full pass even when few pairs rotate; when a sweep gets sparse the
+// solver continues with the moving-index variant (inactive rounds ~10x cheaper) -- at a sweep boundary the position
+// layout is the identity again.
+#define VG_FAST_LOGWAVE 15
+__device__ __forceinline__ int vg_fshift(int u, int n1) { return u == n1 ? n1 : (u == 0 ? n1 - 1 : u - 1); }
+
+struct VgAngle { double c, s, t; bool rot; };
+__device__ __forceinline__ VgAngle vg_angle3(double gpp, double gqq, double gpq, double thr) {
+    VgAngle a{1.0, 0.0, 0.0, fabs(gpq) > thr};
+    if (a.rot) {
+        const double d = gqq - gpp, o = 2.0 * gpq;
+        const double ad = fabs(d), ao = fabs(o);
+        const double ib = vg_rcp(fmax(ad, ao));
+        const double dn = ad * ib, on = ao * ib;
+        const double h2 = dn * dn + on * on;
+        double t = on * vg_rcp(dn + h2 * vg_rsq(h2));
+        if ((d >= 0.0) != (o >= 0.0)) t = -t;
+        a.t = t;
+        a.c = vg_rsq(1.0 + t * t);
+        a.s = t * a.c;
+    }
+    return a;
+}
+
+// returns the buffer that holds G (packed, identity layout, diagonal included) when the phase ends; converged is set
+// when a whole sweep rotated nothing.  Wa must already hold the packed lower triangle.
+__device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, double2* cs, double* Dd, int* nact_s, double thr,
+                                  int& nlog, int& sweeps, int& status, bool& converged) {
+    const int m = J.m, m2 = m + (m & 1), half = m2 >> 1, n1 = m2 - 1;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    // ---- block ownership (constant for the whole phase) ----
+    int rd[2][4], wr[2][4], sal[2], sbe[2];
+    bool ok[2] = {false, false};
+    int sel = 0, dpos = 0, dqos = 0, dpw = 0, dqw = 0, wE = 0;
+    const bool desig = wave == 0 && lane < half;
+    {
+        const int ngen = (half * (half - 1)) / 2 - half;            // blocks that are not designated
+        const int per = nthr - 64;
+        int g[2];
+        if (wave == 0) { g[0] = -1; g[1] = 2 * per + lane; }
+        else { g[0] = tid - 64; g[1] = tid - 64 + per; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int al = 0, be = 0;
+            if (u == 0 && wave == 0) {
+                if (desig) {
+                    const int k = lane;
+                    if (k == 0) { al = 1; be = 0; sel = 1; }
+                    else if (k == 1) { al = 2; be = 0; sel = 0; }
+                    else if (k <= half - 2) { al = k + 1; be = k - 1; sel = 1; }
+                    else { al = half - 1; be = half - 2; sel = 3; }
+                    ok[u] = true;
+                }
+            } else if (g[u] >= 0 && g[u] < ngen) {
+                int rest = g[u];
+                al = 2;
+                for (;;) {
+                    const int cnt = al == half - 1 ? al - 2 : al - 1;
+                    if (rest < cnt) break;
+                    rest -= cnt;
+                    ++al;
+                }
+                be = (al < half - 1 && rest >= al - 2) ? rest + 1 : rest;
+                ok[u] = true;
+            }
+            sal[u] = al; sbe[u] = be;
+            const int pa = al, qa = n1 - al, pb = be, qb = n1 - be;
+            const int pa2 = vg_fshift(pa, n1), qa2 = vg_fshift(qa, n1), pb2 = vg_fshift(pb, n1), qb2 = vg_fshift(qb, n1);
+            rd[u][0] = vg_sym(pa, pb); rd[u][1] = vg_sym(pa, qb); rd[u][2] = vg_sym(qa, pb); rd[u][3] = vg_sym(qa, qb);
+            wr[u][0] = vg_sym(pa2, pb2); wr[u][1] = vg_sym(pa2, qb2); wr[u][2] = vg_sym(qa2, pb2); wr[u][3] = vg_sym(qa2, qb2);
+        }
+        if (desig) {
+            dpos = lane; dqos = n1 - lane;                                  // this lane's pair, in any round's layout
+            dpw = vg_fshift(dpos, n1); dqw = vg_fshift(dqos, n1);           // ... and one round later
+            wE = vg_sym(dpw, dqw);
+        }
+    }
+    double2* cs0 = cs;            // rotations of even rounds
+    double2* cs1 = cs + 256;      // ... of odd rounds
+    double* D0 = Dd;              // diag(G_R) for even R (position layout of round R)
+    double* D1 = Dd + 256;
+    // ---- prologue: rotations of round 0 from the diagonal blocks of the initial matrix ----
+    double eprime = 0.0;
+    if (desig) {
+        const double e = Wa[vg_sym(dpos, dqos)], dp = Wa[vg_tri(dpos) + dpos], dq = Wa[vg_tri(dqos) + dqos];
+        const VgAngle a = vg_angle3(dp, dq, e, thr);
+        cs0[lane] = make_double2(a.c, a.s);
+        D1[dpw] = dp - a.t * e;
+        D1[dqw] = dq + a.t * e;
+        eprime = a.rot ? 0.0 : e;
+        const unsigned long long bal = __ballot(a.rot);
+        if (lane == 0) nact_s[0] = __popcll(bal);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    converged = false;
+    int R = 0;
+    const int switch_below = (n1 * J.fast_switch) >> 8;     // continue here while >= this many rounds of a sweep rotate
+    for (; sweeps < VG_EIG_MAXSWEEP && !status;) {
+        int active_rounds = 0;
+        for (int r = 0; r < n1; ++r, ++R) {
+            const int cur = R & 1;
+            const int na = nact_s[cur];
+            const double* src = cur ? Wb : Wa;
+            double* dst = cur ? Wa : Wb;
+            const double2* csc = cur ? cs1 : cs0;
+            double2* csn = cur ? cs0 : cs1;
+            const double* Dr = cur ? D0 : D1;          // diag(G_{R+1}), written one round ago
+            double* Dw = cur ? D1 : D0;                // receives diag(G_{R+2})
+            if (na > 0) {
+                if (nlog >= J.max_rounds) { status = VGGP_ENOCONV; break; }
+                if (wave == VG_FAST_LOGWAVE) {
+                    // same hand-off as below: publish the count of rounds that are certainly complete, then store
+                    if (lane == 0 && nlog >= VG_EIG_LAG)
+                        __hip_atomic_store(&J.counters[3], nlog - VG_EIG_LAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane < half) {
+                        const double2 v = csc[lane];
+                        double* lp = reinterpret_cast<double*>(&J.rotlog[(long)nlog * half + lane]);
+                        __hip_atomic_store(lp, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(lp + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (lane == 0) __hip_atomic_store(&J.roundlog[nlog], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ++nlog;
+                ++active_rounds;
+            }
+            if (desig) dst[wE] = eprime;               // in-pair element after this round's rotation (0, or untouched)
+            double out0 = 0.0, out1 = 0.0, out2 = 0.0, out3 = 0.0;
+#pragma unroll
+            for (int u = 1; u >= 0; --u) {             // wave 0 does its ordinary half-slot first, the designated blocks last
+                if (!ok[u]) continue;
+                const double g0 = src[rd[u][0]], g1 = src[rd[u][1]], g2 = src[rd[u][2]], g3 = src[rd[u][3]];
+                const double2 A = csc[sal[u]], B = csc[sbe[u]];
+                const double h00 = B.x * g0 - B.y * g1, h01 = B.y * g0 + B.x * g1;
+                const double h10 = B.x * g2 - B.y * g3, h11 = B.y * g2 + B.x * g3;
+                out0 = A.x * h00 - A.y * h10;
+                out2 = A.y * h00 + A.x * h10;
+                out1 = A.x * h01 - A.y * h11;
+                out3 = A.y * h01 + A.x * h11;
+                dst[wr[u][0]] = out0; dst[wr[u][1]] = out1; dst[wr[u][2]] = out2; dst[wr[u][3]] = out3;
+            }
+            if (desig) {
+                // rotation of round R+1 for this lane's pair: its off-diagonal element is one of the outputs above
+                const double e = sel == 0 ? out0 : (sel == 1 ? out1 : out3);
+                const double dp = Dr[dpos], dq = Dr[dqos];
+                const VgAngle a = vg_angle3(dp, dq, e, thr);
+                csn[lane] = make_double2(a.c, a.s);
+                Dw[dpw] = dp - a.t * e;
+                Dw[dqw] = dq + a.t * e;
+                eprime = a.rot ? 0.0 : e;
+                const unsigned long long bal = __ballot(a.rot);
+                if (lane == 0) nact_s[cur ^ 1] = __popcll(bal);
+            }
+            if (wave == VG_FAST_LOGWAVE && na > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (status) break;
+        ++sweeps;
+        if (active_rounds == 0) { converged = true; break; }
+        if (active_rounds < switch_below) break;
+        if (sweeps >= VG_EIG_MAXSWEEP) status = VGGP_ENOCONV;
+    }
+    // ---- epilogue: identity layout again (R is a multiple of n1); restore the diagonal, drain the log wave ----
+    double* Wfin = (R & 1) ? Wb : Wa;
+    const double* Df = (R & 1) ? D1 : D0;
+    if (R == 0) {
+        for (int i = tid; i < m2; i += nthr) (void)i;       // nothing ran: Wa is untouched
+    } else {
+        for (int i = tid; i < m2; i += nthr) Wfin[vg_tri(i) + i] = Df[i];
+    }
+    if (wave == VG_FAST_LOGWAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return Wfin;
+}
+
 template <bool INLDS>
 __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, int* act, unsigned char* isact,
-                               int* nact_s, double* red) {
+                               int* nact_s, double* red, bool fast) {
     const int m = J.m;
     const int m2 = m + (m & 1), half = m2 >> 1;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -126,6 +319,11 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     double fro = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
     const double thr = VG_EIG_TOL * sqrt(fro) / (double)m;
+    int nlog = 0, sweeps = 0, status = 0;
+    bool converged = false;
+    if (INLDS && fast)           // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
+        W = vg_jacobi_fast(J, W, W + ((m2 * (m2 + 1)) >> 1), cs, reinterpret_cast<double*>(pq), nact_s, thr, nlog, sweeps,
+                           status, converged);
 
     // round-independent block -> thread map: canonical blocks (al >= be) enumerated row by row, dealt round-robin
     int my_al[VG_MAXMINE], my_be[VG_MAXMINE];
@@ -152,8 +350,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
 #else
 #define VG_STAMP(var)
 #endif
-    int nlog = 0, sweeps = 0, status = 0;
-    for (int sweep = 0; sweep < VG_EIG_MAXSWEEP; ++sweep) {
+    for (int sweep = sweeps; sweep < VG_EIG_MAXSWEEP && !converged && !status; ++sweep) {
         bool any = false;
         for (int r = 0; r < m2 - 1; ++r) {
             const int par = r & 1;
@@ -881,8 +1078,8 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     const bool block_mode = J.block && J.m <= VG_BJ_MAX_M;
     if (blockIdx.x == 0) {
         if (block_mode) vg_bjacobi_body(J, vg_eig_dyn, cs, pq, nact_s, red);
-        else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red);
-        else vg_jacobi_body<false>(J, J.gwork, cs, pq, act, isact, nact_s, red);
+        else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red, a.fast[blockIdx.y] != 0);
+        else vg_jacobi_body<false>(J, J.gwork, cs, pq, act, isact, nact_s, red, false);
     } else {
         if (block_mode) vg_breplay_body(J, blockIdx.x - 1, vg_eig_dyn, nact_s);
         else vg_replay_body(J, blockIdx.x - 1, a.rp_cols, vg_eig_dyn, nact_s);
@@ -910,6 +1107,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     VgEigArgs a;
     a.njobs = njobs;
+    static const char* fs_env = getenv("VGGP_EIG_FAST_SWITCH");      // tuning / A-B switch (0 disables the dense phase)
     size_t lds = 0;
     int maxm2 = 0;
     for (int j = 0; j < njobs; ++j) maxm2 = jobs[j].m + 1 > maxm2 ? jobs[j].m + 1 : maxm2;
@@ -919,11 +1117,14 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
     maxm2 = 0;
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
+        if (fs_env) a.job[j].fast_switch = atoi(fs_env);
         const int m = jobs[j].m;
         if (m < 1 || m > 256) return hipErrorInvalidValue;
         const int m2 = m + (m & 1);
         a.use_lds[j] = m <= VG_EIG_LDS_MAX_M;
         size_t need = a.use_lds[j] ? (size_t)m2 * (m2 + 1) / 2 * sizeof(double) : 0;
+        a.fast[j] = a.use_lds[j] && !jobs[j].block && a.job[j].fast_switch > 0 && m2 >= 16 && m2 <= 128;
+        if (a.fast[j]) need *= 2;
         size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
         if (jobs[j].block && m <= VG_BJ_MAX_M) {
             const size_t nb = 2 * ((m + 31) / 32), Mp = 16 * nb, np = nb / 2;
