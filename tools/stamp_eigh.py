@@ -26,11 +26,16 @@ lam, Qt, sw = e.eigh(Gd)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 lam, Qt, sw = e.eigh(Gd)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-buf = (C.c_uint64 * 64)()
+buf = (C.c_uint64 * 128)()
 e.lib.vggp_debug_read_misc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-e.lib.vggp_debug_read_misc(e._h, buf, 64 * 8)
-a = np.array(list(buf)).reshape(16, 4).astype(float)
+e.lib.vggp_debug_read_misc(e._h, buf, 128 * 8)
+b = np.array(list(buf)).astype(float)
+a = b[:64].reshape(16, 4)
+f = b[64:].reshape(16, 4)
 nr = sw * (m - 1)
 print(f"sweeps {sw} rounds {nr} wall {dt*1e6:.0f} us (incl. launch+sync)")
 for w in (0, 1, 8, 15):
     print("wave", w, "totals kcycles [P, bar1, U, bar2]:", (a[w] / 1e3).round(1), "sum", round(a[w].sum() / 1e3, 1), "per round", (a[w] / nr).round(0))
+for w in (0, 1, 8, 15):
+    n = max(f[w, 3], 1)
+    print("fast wave", w, "rounds", int(f[w, 3]), "per round [update, angle, barrier]:", (f[w, :3] / n).round(0), "total kcycles", round(f[w, :3].sum() / 1e3, 1))

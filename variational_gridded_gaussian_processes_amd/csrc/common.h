@@ -116,6 +116,7 @@ struct VgEigJob {
     int max_rounds;
     long log_bytes;       // size of the rotlog buffer in bytes (vg_eigh_log_bytes(m))
     int block;            // 1: block-Jacobi variant (m <= 128), 0: scalar cyclic Jacobi
+    double tol = 0.0;     // off-diagonal threshold relative to ||G||_F / m (0: VG_EIG_TOL)
     int fast_switch = 128; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's rounds rotate; 0 = off
 };
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)

@@ -16,7 +16,7 @@
 
 #include <cstdlib>
 
-#define VG_EIG_TOL 1e-13
+#define VG_EIG_TOL 1e-13         // default relative off-diagonal threshold (VgEigJob::tol)
 #ifndef VG_BJ_MAX_M
 #define VG_BJ_MAX_M 128            // block Jacobi up to this size, scalar cyclic Jacobi beyond
 #endif
@@ -122,6 +122,11 @@ __device__ __forceinline__ void vg_round_barrier() {
 // the log format are unchanged.  A round costs a full pass even when few pairs rotate; when a sweep gets sparse the
 // solver continues with the moving-index variant (inactive rounds ~10x cheaper) -- at a sweep boundary the position
 // layout is the identity again.
+#ifdef VG_EIG_STAMP
+#define VG_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VG_STAMP(var)
+#endif
 #define VG_FAST_LOGWAVE 15
 __device__ __forceinline__ int vg_fshift(int u, int n1) { return u == n1 ? n1 : (u == 0 ? n1 - 1 : u - 1); }
 
@@ -215,11 +220,17 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     converged = false;
     int R = 0;
+#ifdef VG_EIG_STAMP
+    unsigned long long fU = 0, fA = 0, fB = 0, fN = 0, fs0, fs1;
+#endif
     const int switch_below = (n1 * J.fast_switch) >> 8;     // continue here while >= this many rounds of a sweep rotate
     for (; sweeps < VG_EIG_MAXSWEEP && !status;) {
         int active_rounds = 0;
         for (int r = 0; r < n1; ++r, ++R) {
             const int cur = R & 1;
+#ifdef VG_EIG_STAMP
+            VG_STAMP(fs0);
+#endif
             const int na = nact_s[cur];
             const double* src = cur ? Wb : Wa;
             double* dst = cur ? Wa : Wb;
@@ -259,6 +270,9 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
                 out3 = A.y * h01 + A.x * h11;
                 dst[wr[u][0]] = out0; dst[wr[u][1]] = out1; dst[wr[u][2]] = out2; dst[wr[u][3]] = out3;
             }
+#ifdef VG_EIG_STAMP
+            VG_STAMP(fs1); fU += fs1 - fs0;
+#endif
             if (desig) {
                 // rotation of round R+1 for this lane's pair: its off-diagonal element is one of the outputs above
                 const double e = sel == 0 ? out0 : (sel == 1 ? out1 : out3);
@@ -271,8 +285,14 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
                 const unsigned long long bal = __ballot(a.rot);
                 if (lane == 0) nact_s[cur ^ 1] = __popcll(bal);
             }
+#ifdef VG_EIG_STAMP
+            VG_STAMP(fs0); fA += fs0 - fs1;
+#endif
             if (wave == VG_FAST_LOGWAVE && na > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef VG_EIG_STAMP
+            VG_STAMP(fs1); fB += fs1 - fs0; ++fN;
+#endif
         }
         if (status) break;
         ++sweeps;
@@ -281,6 +301,12 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
         if (sweeps >= VG_EIG_MAXSWEEP) status = VGGP_ENOCONV;
     }
     // ---- epilogue: identity layout again (R is a multiple of n1); restore the diagonal, drain the log wave ----
+#ifdef VG_EIG_STAMP
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(J.gwork) + 64 + wave * 4;
+        dbg[0] = fU; dbg[1] = fA; dbg[2] = fB; dbg[3] = fN;
+    }
+#endif
     double* Wfin = (R & 1) ? Wb : Wa;
     const double* Df = (R & 1) ? D1 : D0;
     if (R == 0) {
@@ -318,7 +344,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     __syncthreads();
     double fro = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
-    const double thr = VG_EIG_TOL * sqrt(fro) / (double)m;
+    const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
     int nlog = 0, sweeps = 0, status = 0;
     bool converged = false;
     if (INLDS && fast)           // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
@@ -346,9 +372,6 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
 
 #ifdef VG_EIG_STAMP
     unsigned long long tP = 0, tB1 = 0, tU = 0, tB2 = 0, t0s, t1s;
-#define VG_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define VG_STAMP(var)
 #endif
     for (int sweep = sweeps; sweep < VG_EIG_MAXSWEEP && !converged && !status; ++sweep) {
         bool any = false;
@@ -692,7 +715,7 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
     __syncthreads();
     double fro = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
-    const double thr = VG_EIG_TOL * sqrt(fro) / (double)m;
+    const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
 
     // capacity of the log buffer in outer rounds (it was sized for the scalar kernel's (c, s) log)
     const int cap_rounds = (int)(J.log_bytes / ((long)npair * 1024 * sizeof(double)));
@@ -1108,6 +1131,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
     VgEigArgs a;
     a.njobs = njobs;
     static const char* fs_env = getenv("VGGP_EIG_FAST_SWITCH");      // tuning / A-B switch (0 disables the dense phase)
+    static const char* tol_env = getenv("VGGP_EIG_TOL");
     size_t lds = 0;
     int maxm2 = 0;
     for (int j = 0; j < njobs; ++j) maxm2 = jobs[j].m + 1 > maxm2 ? jobs[j].m + 1 : maxm2;
@@ -1118,6 +1142,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         if (fs_env) a.job[j].fast_switch = atoi(fs_env);
+        if (tol_env) a.job[j].tol = atof(tol_env);
         const int m = jobs[j].m;
         if (m < 1 || m > 256) return hipErrorInvalidValue;
         const int m2 = m + (m & 1);
