@@ -1,0 +1,24 @@
+"""Per-kernel timeline of ONE steady-state ELBO step from a rocprofv3 --kernel-trace CSV (graph replay):
+start offsets, durations and the idle gaps between consecutive kernels.  usage: trace_step.py <dir>"""
+import csv, glob, os, sys
+f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("vg_")]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# a step starts with vg_factor_kernel; take the median-length step among the last 50
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("vg_factor_kernel")]
+steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
+steps = [s for s in steps if s[1] - s[0] == max(set(b - a for a, b in steps), key=[b - a for a, b in steps].count)][-50:]
+def span(s):
+    return int(rows[s[1] - 1]["End_Timestamp"]) - int(rows[s[0]]["Start_Timestamp"])
+steps.sort(key=span)
+a, b = steps[len(steps) // 2]
+t0 = int(rows[a]["Start_Timestamp"])
+prev_end = t0
+tot_k = 0
+print(f"median step: {b - a} kernels, span {span((a, b)) / 1e3:.1f} us")
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print(f"{(s - t0) / 1e3:9.1f} us  +gap {(s - prev_end) / 1e3:6.1f}  dur {(e - s) / 1e3:7.1f}  {r['Kernel_Name'].split('(')[0]:22s} grid {r.get('Grid_Size', '?')}")
+    prev_end = max(prev_end, e)
+    tot_k += e - s
+print(f"sum of kernel durations {tot_k / 1e3:.1f} us")

@@ -20,6 +20,9 @@
 // order (slow; only used by the building-block API for large matrices).
 #include "common.h"
 
+#include <cstdlib>
+
+static const int VG_CHOL_FAST_MAX_M = 128;      // fast paths: matrix resident in the LDS of one CU
 __constant__ double VG_JITTERS[4] = {0.0, 1e-8, 1e-7, 1e-6};
 
 struct VgCholArgs {
@@ -285,6 +288,276 @@ __device__ void vg_chol_generic(const VgCholJob& J, double* sd) {
     }
 }
 
+
+// ==== MFMA-blocked path (m <= 128): left-looking Cholesky on 16-wide panels ==========================================
+// One workgroup of 8 waves per (matrix, jitter level); the matrix (lower triangle, padded to 16 nb) lives in LDS.
+// Per panel p:   (1) wave w forms the transposed Schur block U^T of block row bi = p + w with f64 MFMAs
+//                    (U^T = K[bi][p]^T - L[p][:p] L[bi][:p]^T, accumulators only);
+//                (2) wave 0 factors the 16 x 16 diagonal block: 16 pivot steps entirely inside the wave (no workgroup
+//                    barrier; the pivot column and the pivot row of the running inverse travel through LDS), giving
+//                    L11 and X11 = L11^{-1} (Gaussian elimination on [A | I], rows scaled by 1/sqrt(pivot) at the end);
+//                (3) the other waves finish their block: L[bi][p]^T = X11 U^T -- U^T is still in the accumulator
+//                    registers, whose layout is exactly the MFMA B operand, so this is 4 MFMAs and no LDS round trip.
+// Two workgroup barriers per panel instead of one per column: the factorisation's critical path is the 16 in-wave pivot
+// steps per panel.  The full inverse follows blockwise, X[bi][bj] = -X[bi][bi] sum_{bj<=bk<bi} L[bi][bk] X[bk][bj]; block
+// column bj is owned by wave bj, so this phase needs no barrier at all.  X blocks live in the unused upper block triangle.
+#define VG_CB 16
+#define VG_CLD 132                         // LDS row stride (doubles): 16 rows x 4 k of an MFMA operand hit 32 distinct banks per half-wave
+typedef double vg_cd4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double vg_crcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double vg_crsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(y * 0.5, fma(-x * y, y, 1.0), y);
+    y = fma(y * 0.5, fma(-x * y, y, 1.0), y);
+    return y;
+}
+#define VG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Dinv, double* Db, double* colbuf, double* xrow,
+                             double* sdv, int* s_i) {
+    const int m = J.m, nb = (m + VG_CB - 1) / VG_CB, mp = nb * VG_CB;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fk = lane >> 4;
+    const double jit = VG_JITTERS[lvl];
+    const int ldk = J.ldk ? J.ldk : m, ldl = J.ldl ? J.ldl : m;
+    int* flags = reinterpret_cast<int*>(J.scratch);          // [4] per matrix, zeroed by the CALLER before the launch
+#ifdef VG_CHOL_STAMP
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tF = 0, tU = 0, tS = 0, q0, q1;
+#define CM(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    CM(T[0]);
+#else
+#define CM(var)
+#endif
+
+    // lower triangle of K (+ jitter), identity on the padding; everything above the diagonal blocks starts at zero.
+    // A wave takes whole rows (coalesced, no integer division); four rows' loads are in flight together.
+    {
+        const int nw = nthr >> 6;
+        for (int i0 = wave; i0 < mp; i0 += 4 * nw) {
+            double v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nw;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = lane + 64 * h;
+                    double x = 0.0;
+                    if (i < m && j <= i) x = J.K[(long)i * ldk + j];
+                    v[u][h] = x;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nw;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = lane + 64 * h;
+                    if (i < mp && j < mp) Lm[i * VG_CLD + j] = v[u][h] + (i == j ? (i < m ? jit : 1.0) : 0.0);
+                }
+            }
+        }
+    }
+    for (int idx = tid; idx < nb * VG_CB * VG_CB; idx += nthr) Dinv[idx] = 0.0;
+    if (tid == 0) s_i[2] = 0;
+    __syncthreads();
+    CM(T[1]);
+
+    bool ok = true;
+    for (int p = 0; p < nb; ++p) {
+        CM(q0);
+        const int bi = p + wave;
+        vg_cd4 ut = {0.0, 0.0, 0.0, 0.0};
+        const bool mine = bi < nb;
+        if (mine) {
+            // acc[c][i] = sum_k L[16p + c][k] L[16bi + i][k],  k < 16p
+            vg_cd4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* ap = Lm + (p * VG_CB + fi) * VG_CLD + fk;
+            const double* bp = Lm + (bi * VG_CB + fi) * VG_CLD + fk;
+            for (int k0 = 0; k0 < p * VG_CB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = fk + 4 * r, i = fi;                    // D layout: row c (panel column), col i (row inside block bi)
+                int gr = bi * VG_CB + i, gc = p * VG_CB + c;
+                if (gc > gr) { const int t = gr; gr = gc; gc = t; }  // diagonal block: symmetric, stored lower
+                ut[r] = Lm[gr * VG_CLD + gc] - acc[r];
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Db[(fk + 4 * r) * 17 + fi] = ut[r];
+            }
+        }
+        CM(q1);
+#ifdef VG_CHOL_STAMP
+        tU += q1 - q0;
+#endif
+        if (wave == 0) {
+            // ---- 16 x 16 diagonal block: in-wave elimination on [A | I]; lane (i, q) holds columns 4q .. 4q+3 of row i ----
+            VG_WAVE_SYNC();
+            const int i = fi, q = fk;
+            double a[4], x[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { a[c] = Db[i * 17 + 4 * q + c]; x[c] = (i == 4 * q + c) ? 1.0 : 0.0; }
+            bool good = true;
+#pragma unroll
+            for (int k = 0; k < VG_CB; ++k) {
+                if (q == (k >> 2)) colbuf[k * 16 + i] = a[k & 3];
+                if (i == k) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xrow[(k & 1) * 16 + 4 * q + c] = x[c];
+                }
+                VG_WAVE_SYNC();
+                const double piv = colbuf[k * 16 + k], li = colbuf[k * 16 + i];
+                double lj[4], xr[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { lj[c] = colbuf[k * 16 + 4 * q + c]; xr[c] = xrow[(k & 1) * 16 + 4 * q + c]; }
+                if (!(piv > 0.0) || !(piv < 1.0e300)) { good = false; break; }     // wave-uniform
+                const double lr = (i > k) ? li * vg_crcp(piv) : 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { a[c] -= lr * lj[c]; x[c] -= lr * xr[c]; }
+            }
+            if (good) {
+                if (lane < 16) sdv[lane] = vg_crsq(colbuf[lane * 16 + lane]);      // 1 / L[k][k]
+                VG_WAVE_SYNC();
+                const double si = sdv[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = 4 * q + c;
+                    Lm[(p * VG_CB + i) * VG_CLD + p * VG_CB + k] = (k <= i) ? colbuf[k * 16 + i] * sdv[k] : 0.0;
+                    Dinv[(p * VG_CB + i) * VG_CB + k] = (k <= i) ? x[c] * si : 0.0;
+                }
+            } else if (lane == 0) {
+                s_i[2] = 1;
+            }
+        }
+        CM(q0);
+#ifdef VG_CHOL_STAMP
+        tF += q0 - q1;
+#endif
+        __syncthreads();
+        if (s_i[2]) { ok = false; break; }
+        if (mine && wave > 0) {
+            // L[bi][p]^T = X11 U^T : A operand X11[c'][k] from LDS, B operand for k-step r is accumulator register r of U^T
+            vg_cd4 lt = {0.0, 0.0, 0.0, 0.0};
+            const double* xp = Dinv + (p * VG_CB + fi) * VG_CB + fk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lt = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * r], ut[r], lt, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Lm[(bi * VG_CB + fi) * VG_CLD + p * VG_CB + fk + 4 * r] = lt[r];
+        }
+        __syncthreads();
+        CM(q1);
+#ifdef VG_CHOL_STAMP
+        tS += q1 - q0;
+#endif
+    }
+    CM(T[2]);
+
+    // ---- level selection: the lowest successful level wins (relaxed agent-scope flags, no payload) ----------
+    if (J.only_level0) {
+        if (tid == 0) { s_i[0] = ok ? 1 : 0; s_i[1] = ok ? 0 : 1; }
+    } else if (tid == 0) {
+        __hip_atomic_store(&flags[lvl], ok ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int win = ok ? 1 : 0, spins = 0;
+        bool all_failed = !ok;
+        for (int l = 0; l < lvl; ++l) {
+            int f;
+            while ((f = __hip_atomic_load(&flags[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                if (++spins > (1 << 22)) { f = 2; break; }   // bounded: a missing sibling counts as failed
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (f == 1) { win = 0; all_failed = false; }
+        }
+        s_i[0] = win;
+        s_i[1] = (lvl == 3 && all_failed) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool winner = s_i[0] != 0, report_fail = s_i[1] != 0;
+    if (report_fail) {
+        if (tid == 0) { *J.status = VGGP_ENOTPD; if (J.jitter_out) *J.jitter_out = -1.0; }
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int idx = tid; idx < m * m; idx += nthr) { J.L[(long)(idx / m) * ldl + idx % m] = qnan; J.Linv[idx] = qnan; }
+    }
+    if (!winner) return;
+    if (tid == 0 && J.jitter_out) *J.jitter_out = jit;
+    CM(T[3]);
+
+    // ---- L out (the upper block triangle of Lm is about to receive X) ----
+    for (int i = wave; i < m; i += (nthr >> 6))
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = lane + 64 * h;
+            if (j < m) J.L[(long)i * ldl + j] = (j <= i) ? Lm[i * VG_CLD + j] : 0.0;
+        }
+    CM(T[4]);
+    // ---- X = L^{-1}: block column bj by wave bj, rows top-down; X[bi][bj] is kept at block position (bj, bi) ----
+    for (int bj = wave; bj < nb; bj += (nthr >> 6)) {
+        for (int bi = bj + 1; bi < nb; ++bi) {
+            vg_cd4 t = {0.0, 0.0, 0.0, 0.0};
+            const double* ap = Lm + (bi * VG_CB + fi) * VG_CLD + fk;                 // L[16bi + i][k]
+            // bk = bj: X[bj][bj] = Dinv block
+            {
+                const double* bp = Dinv + (bj * VG_CB + fk) * VG_CB + fi;            // X11[k][j]
+#pragma unroll
+                for (int k0 = 0; k0 < VG_CB; k0 += 4)
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[bj * VG_CB + k0], bp[k0 * VG_CB], t, 0, 0, 0);
+            }
+            for (int bk = bj + 1; bk < bi; ++bk) {
+                const double* bp = Lm + (bj * VG_CB + fk) * VG_CLD + bk * VG_CB + fi;    // X[bk][bj][k][j] at (16bj + k, 16bk + j)
+#pragma unroll
+                for (int k0 = 0; k0 < VG_CB; k0 += 4)
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[bk * VG_CB + k0], bp[k0 * VG_CLD], t, 0, 0, 0);
+            }
+            vg_cd4 xb = {0.0, 0.0, 0.0, 0.0};
+            const double* xp = Dinv + (bi * VG_CB + fi) * VG_CB + fk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * r], t[r], xb, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Lm[(bj * VG_CB + fk + 4 * r) * VG_CLD + bi * VG_CB + fi] = -xb[r];
+            VG_WAVE_SYNC();                                                        // own stores before own next-row loads
+        }
+    }
+    __syncthreads();
+    CM(T[5]);
+    for (int i = wave; i < m; i += (nthr >> 6))
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = lane + 64 * h;
+            const int bi = i >> 4, bj = j >> 4;
+            double v = 0.0;
+            if (bi == bj) v = Dinv[i * VG_CB + (j & 15)];
+            else if (bi > bj) v = Lm[(bj * VG_CB + (i & 15)) * VG_CLD + bi * VG_CB + (j & 15)];
+            if (j < m) J.Linv[(long)i * m + j] = v;
+        }
+#ifdef VG_CHOL_STAMP
+    CM(T[6]);
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(J.scratch) + 16 + wave * 12;
+        for (int i = 0; i < 7; ++i) dbg[i] = T[i] - T[0];
+        dbg[7] = tU; dbg[8] = tF; dbg[9] = tS;
+    }
+#endif
+}
+
+__global__ __launch_bounds__(512) void vg_chol_mfma_kernel(const VgCholArgs a) {
+    extern __shared__ double vg_cm_dyn[];
+    __shared__ double Db[16 * 17];
+    __shared__ double colbuf[16 * 16];
+    __shared__ double xrow[2 * 16];
+    __shared__ double sdv[16];
+    __shared__ int s_i[4];
+    const VgCholJob& J = a.job[blockIdx.y];
+    const int lvl = blockIdx.x;
+    if (J.only_level0 && lvl > 0) return;
+    const int nb = (J.m + VG_CB - 1) / VG_CB, mp = nb * VG_CB;
+    vg_chol_mfma(J, lvl, vg_cm_dyn, vg_cm_dyn + mp * VG_CLD, Db, colbuf, xrow, sdv, s_i);
+}
+
 __global__ __launch_bounds__(1024) void vg_chol_kernel(const VgCholArgs a) {
     extern __shared__ double vg_chol_dyn[];
     __shared__ double sd[1024];
@@ -301,9 +574,11 @@ __global__ __launch_bounds__(1024) void vg_chol_kernel(const VgCholArgs a) {
     }
 }
 
-static const int VG_CHOL_FAST_MAX_M = 128;      // 4 x 4 register tile per thread; LDS holds the padded packed triangle
 
 hipError_t vg_chol_setup() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_chol_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_chol_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
 }
@@ -313,6 +588,20 @@ hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
     VgCholArgs a;
     a.njobs = njobs;
     size_t lds = 0;
+    static const bool legacy = getenv("VGGP_CHOL_LEGACY") != nullptr;      // A/B switch: register-resident column kernel
+    bool all_fast = !legacy;
+    for (int j = 0; j < njobs; ++j) all_fast = all_fast && jobs[j].m >= 1 && jobs[j].m <= VG_CHOL_FAST_MAX_M;
+    if (all_fast) {
+        for (int j = 0; j < njobs; ++j) {
+            a.job[j] = jobs[j];
+            a.fast[j] = 1;
+            const size_t mp = (size_t)((jobs[j].m + VG_CB - 1) / VG_CB) * VG_CB;
+            const size_t need = (mp * VG_CLD + mp * VG_CB) * sizeof(double);
+            if (need > lds) lds = need;
+        }
+        hipLaunchKernelGGL(vg_chol_mfma_kernel, dim3(4, njobs), dim3(512), lds, st, a);
+        return hipGetLastError();
+    }
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         if (jobs[j].m > 1024 || jobs[j].m < 1) return hipErrorInvalidValue;

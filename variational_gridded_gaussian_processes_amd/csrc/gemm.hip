@@ -20,14 +20,24 @@
 
 typedef double vg_d4 __attribute__((ext_vector_type(4)));
 
-#define LDS_KMAJ_STRIDE (VG_BM + 16)   // [k][i]
-#define LDS_RMAJ_STRIDE (VG_BK + 1)    // [i][k]
-#define LDS_TILE 1280                   // max(16*80, 64*17) doubles
+// Tile configurations: <T = 64, BK = 16> for the contractions over the grid (MFMA-bound: 16 MFMAs per wave and k-tile),
+// <T = 32, BK = 32> for the m x m x m chain products (latency-bound: 4x the workgroups, half the k-tiles).
+// Both move T*BK = 1024 elements per operand and k-tile, i.e. 4 per thread.
+template <int T, int BK>
+struct VgTile {
+    static constexpr int RPAD = BK == 16 ? 1 : 4;            // K-contiguous operand: LDS [row][BK + RPAD]
+    static constexpr int RS = BK + RPAD;
+    static constexpr int KS = T + 16;                        // M/N-contiguous operand: LDS [k][T + 16]
+    static constexpr int TILE = (BK * KS > T * RS) ? BK * KS : T * RS;
+    static constexpr int MB = T / 32;                        // 16 x 16 MFMA blocks per wave and dimension
+};
 
-__global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
-    __shared__ double lds[2 * LDS_TILE];
+template <int T, int BK>
+__device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) {
+    using C_ = VgTile<T, BK>;
+    constexpr int MB = C_::MB;
     double* As = lds;
-    double* Bs = lds + LDS_TILE;
+    double* Bs = lds + C_::TILE;
 
     const int bid = blockIdx.x;
     int pi = 0;
@@ -40,7 +50,7 @@ __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
     const int ks = t / tiles;
     t -= ks * tiles;
     const int tm = t / p.tiles_n, tn = t - (t / p.tiles_n) * p.tiles_n;
-    const int row0 = tm * VG_BM, col0 = tn * VG_BN;
+    const int row0 = tm * T, col0 = tn * T;
     const int k_begin = ks * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
 
@@ -57,64 +67,74 @@ __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
     const int nslab = p.b_nslab;
     const long bslab = p.b_slab;
 
-    // global->register mapping for the 64x16 A tile and 16x64 B tile: 4 elements each
+    // global->register mapping for the T x BK A tile and BK x T B tile: 4 elements each
     int a_i[4], a_k[4], b_k[4], b_j[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (a_kc) { a_k[r] = tid & 15; a_i[r] = (tid >> 4) + 16 * r; }
-        else      { a_i[r] = tid & 63; a_k[r] = (tid >> 6) + 4 * r; }
-        if (b_nc) { b_j[r] = tid & 63; b_k[r] = (tid >> 6) + 4 * r; }
-        else      { b_k[r] = tid & 15; b_j[r] = (tid >> 4) + 16 * r; }
+        if (a_kc) { a_k[r] = tid % BK; a_i[r] = tid / BK + (256 / BK) * r; }
+        else      { a_i[r] = tid % T; a_k[r] = tid / T + (256 / T) * r; }
+        if (b_nc) { b_j[r] = tid % T; b_k[r] = tid / T + (256 / T) * r; }
+        else      { b_k[r] = tid % BK; b_j[r] = tid / BK + (256 / BK) * r; }
     }
-    const int a_si = a_kc ? LDS_RMAJ_STRIDE : 1, a_sk = a_kc ? 1 : LDS_KMAJ_STRIDE;
-    const int b_sj = b_nc ? 1 : LDS_RMAJ_STRIDE, b_sk = b_nc ? LDS_KMAJ_STRIDE : 1;
+    const int a_si = a_kc ? C_::RS : 1, a_sk = a_kc ? 1 : C_::KS;
+    const int b_sj = b_nc ? 1 : C_::RS, b_sk = b_nc ? C_::KS : 1;
 
     double ra[4], rb[4];
     auto load_tile = [&](int k0) {
+        const double* bp[4];
+        bool bok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gi = row0 + a_i[r], gk = k0 + a_k[r];
             ra[r] = (gi < M && gk < k_end) ? A[gi * sa_m + gk * sa_k] : 0.0;
             const int gj = col0 + b_j[r], gkb = k0 + b_k[r];
-            double v = 0.0;
-            if (gj < N && gkb < k_end) {
-                const double* bp = B + gkb * sb_k + gj * sb_n;
-                v = bp[0];
-                for (int s = 1; s < nslab; ++s) v += bp[s * bslab];
-            }
-            rb[r] = v;
+            bok[r] = gj < N && gkb < k_end;
+            bp[r] = B + (bok[r] ? gkb * sb_k + gj * sb_n : 0);
+            rb[r] = bok[r] ? bp[r][0] : 0.0;
+        }
+        // B given as a sum of slabs (the producer's split-K partials): all 4 elements of up to 3 further slabs are
+        // in flight together -- a load-add chain per slab would expose one L2 round trip per slab and element
+        for (int s = 1; s < nslab; s += 3) {
+            double t[3][4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[u][r] = (bok[r] && s + u < nslab) ? bp[r][(long)(s + u) * bslab] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rb[r] += (t[0][r] + t[1][r]) + t[2][r];
         }
     };
 
-    vg_d4 acc[2][2];
+    vg_d4 acc[MB][MB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (vg_d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < MB; ++j) acc[i][j] = (vg_d4){0.0, 0.0, 0.0, 0.0};
 
     const int fi = lane & 15, fk = lane >> 4;
+    constexpr int WT = T / 2;                                  // rows / cols per wave
     if (k_begin < k_end) load_tile(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += VG_BK) {
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             As[a_i[r] * a_si + a_k[r] * a_sk] = ra[r];
             Bs[b_k[r] * b_sk + b_j[r] * b_sj] = rb[r];
         }
         __syncthreads();
-        if (k0 + VG_BK < k_end) load_tile(k0 + VG_BK);   // in flight while the MFMAs run
+        if (k0 + BK < k_end) load_tile(k0 + BK);   // in flight while the MFMAs run
 #pragma unroll
-        for (int kk = 0; kk < VG_BK; kk += 4) {
-            double av[2], bv[2];
+        for (int kk = 0; kk < BK; kk += 4) {
+            double av[MB], bv[MB];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                av[mb] = As[(wr * 32 + mb * 16 + fi) * a_si + (kk + fk) * a_sk];
+            for (int mb = 0; mb < MB; ++mb)
+                av[mb] = As[(wr * WT + mb * 16 + fi) * a_si + (kk + fk) * a_sk];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                bv[nb] = Bs[(kk + fk) * b_sk + (wc * 32 + nb * 16 + fi) * b_sj];
+            for (int nb = 0; nb < MB; ++nb)
+                bv[nb] = Bs[(kk + fk) * b_sk + (wc * WT + nb * 16 + fi) * b_sj];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < MB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
         }
         __syncthreads();
@@ -123,19 +143,28 @@ __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
     double* __restrict__ C = p.C + (long)ks * p.c_slab;
     const int ldc = p.ldc;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < MB; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + wr * 32 + mb * 16 + fk + 4 * r;
-                const int col = col0 + wc * 32 + nb * 16 + fi;
+                const int row = row0 + wr * WT + mb * 16 + fk + 4 * r;
+                const int col = col0 + wc * WT + nb * 16 + fi;
                 if (row < M && col < N) {
                     double* cp = C + (long)row * ldc + col;
                     const double v = p.alpha * acc[mb][nb][r];
                     *cp = p.accum ? *cp + v : v;
                 }
             }
+}
+
+__global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
+    __shared__ double lds[2 * VgTile<64, 16>::TILE];
+    vg_gemm_body<64, 16>(b, lds);
+}
+__global__ __launch_bounds__(256) void vg_gemm_small_kernel(const VgGemmBatch b) {
+    __shared__ double lds[2 * VgTile<32, 32>::TILE];
+    vg_gemm_body<32, 32>(b, lds);
 }
 
 void vg_gemm_init(VgGemmBatch* b) {
@@ -172,6 +201,24 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
 
 hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st) {
     if (b->nprob == 0 || b->total_tiles == 0) return hipSuccess;
+    // a batch that cannot fill half the chip with 64 x 64 tiles and is not split-K (the m x m x m chain products) runs
+    // with 32 x 32 tiles: 4x the workgroups, each with a quarter of the MFMA work per k-tile
+    bool small = b->total_tiles < 128;
+    for (int i = 0; i < b->nprob; ++i) small = small && b->p[i].ksplit == 1 && b->p[i].K <= 512;
+    if (small) {
+        VgGemmBatch s = *b;
+        s.total_tiles = 0;
+        for (int i = 0; i < s.nprob; ++i) {
+            VgGemmP& p = s.p[i];
+            p.tiles_m = (p.M + 31) / 32;
+            p.tiles_n = (p.N + 31) / 32;
+            p.kchunk = ((p.K + 31) / 32) * 32;
+            p.tile_start = s.total_tiles;
+            s.total_tiles += p.tiles_m * p.tiles_n;
+        }
+        hipLaunchKernelGGL(vg_gemm_small_kernel, dim3(s.total_tiles), dim3(256), 0, st, s);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(vg_gemm_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
     return hipGetLastError();
 }
