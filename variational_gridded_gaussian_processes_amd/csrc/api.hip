@@ -70,6 +70,10 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
     VG_HIP(hipStreamCreate(&c->own_stream));
     VG_HIP(hipHostMalloc((void**)&c->h_theta, 8 * sizeof(double), hipHostMallocDefault));
     VG_HIP(hipHostMalloc((void**)&c->h_out, sizeof(HostOut), hipHostMallocDefault));
+    VG_HIP(hipHostGetDevicePointer((void**)&c->d_hout, c->h_out, 0));
+    VG_HIP(hipHostGetDevicePointer((void**)&c->d_htheta, c->h_theta, 0));
+    VG_HIP(hipMalloc((void**)&c->ticket, 4 * sizeof(int)));
+    VG_HIP(hipMemset(c->ticket, 0, 4 * sizeof(int)));
     VG_HIP(hipMalloc((void**)&c->sumsq_partial, 1024 * sizeof(double)));
     VG_HIP(hipMalloc((void**)&c->sumsq_out, 8 * sizeof(double)));
     *out = c;
@@ -86,6 +90,7 @@ extern "C" int vggp_destroy(vggp_ctx* c) {
     if (c->misc) (void)hipFree(c->misc);
     if (c->h_theta) (void)hipHostFree(c->h_theta);
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->ticket) (void)hipFree(c->ticket);
     if (c->sumsq_partial) (void)hipFree(c->sumsq_partial);
     if (c->sumsq_out) (void)hipFree(c->sumsq_out);
     delete c;
@@ -247,32 +252,29 @@ extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t
 // Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
 // caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st) {
-    VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     VG_MARK(0);
 
-    // 1. factor build (unit outputscale): A0|dA0, K0, dK0 for both dimensions
+    // 1. factor build (unit outputscale): A0|dA0, K0, dK0 for both dimensions.  First node of the step: it reads the
+    //    hyper-parameters from the pinned host block (and leaves a device copy for the later kernels), and its block 0
+    //    zeroes the status words, the jitter-level flags and the Jacobi progress words of the step.
     VgFactorJob fj[2];
-    for (int k = 0; k < 2; ++k) {
-        VgDim& d = c->d[k];
-        fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0, c->desc.flags};
-    }
-    VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
-    VG_MARK(1);
-
-    // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
     VgCholJob cj[2];
     VgClearArgs clr;
     clr.n = 0;
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
+        fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0, c->desc.flags};
         clr.ptr[clr.n] = d.status; clr.nwords[clr.n++] = 2;
         clr.ptr[clr.n] = reinterpret_cast<int*>(d.chol_scratch); clr.nwords[clr.n++] = 16;     // jitter-level flags
         clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 4;                                  // Jacobi progress word
         cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
     }
-    VG_HIP(vg_clear_launch(&clr, st));
+    VG_HIP(vg_factor_build_launch(fj, 2, c->d_htheta, st, c->theta, &clr));
+    VG_MARK(1);
+
+    // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
     VG_HIP(vg_chol_launch(cj, 2, st));
     VG_MARK(2);
 
@@ -324,8 +326,10 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     return VGGP_OK;
 }
 
-static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st) {
-    VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
+static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta) {
+    // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
+    // factor kernel already did
+    if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     const double* G0[2] = {d1.GH, payload};
@@ -356,6 +360,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
                          (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
+        ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -392,6 +397,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     ms.rowpart = c->rowpart; ms.r1 = c->r1; ms.r1l = c->r1l; ms.out = c->out;
     ms.r2 = c->r2; ms.r2l = c->r2l; ms.dotpart = c->dotpart;
     ms.m1 = (int)m1; ms.m2 = (int)m2; ms.n_total = (double)c->desc.n_total; ms.yy = yy_total;
+    ms.ticket = c->ticket; ms.hout = c->d_hout;
+    for (int k = 0; k < 2; ++k) { ms.jit[k] = c->d[k].jitter; ms.status[k] = c->d[k].status; ms.counters[k] = c->d[k].counters; }
     VG_HIP(vg_dstage_launch(&ms, st));
     VG_MARK(12);
     vg_gemm_init(&g);
@@ -404,16 +411,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     VG_HIP(vg_final_launch(&ms, st));
     VG_MARK(14);
 
-    // 10. keep this step's basis for the next warm start / q(v) / posterior, and stage the 6 result doubles +
-    //     diagnostics to pinned host memory (read after the step's only host sync)
-    for (int k = 0; k < 2; ++k) {
-        VgDim& d = c->d[k];
-        VG_HIP(hipMemcpyAsync(d.QtPrev, d.Qt, sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
-        VG_HIP(hipMemcpyAsync(&c->h_out->jitter[k], d.jitter, sizeof(double), hipMemcpyDeviceToHost, st));
-        VG_HIP(hipMemcpyAsync(c->h_out->counters[k], d.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-        VG_HIP(hipMemcpyAsync(&c->h_out->status[k], d.status, sizeof(int), hipMemcpyDeviceToHost, st));
-    }
-    VG_HIP(hipMemcpyAsync(c->h_out->out, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    // 10. nothing to copy: the replay workgroups already left the new basis in QtPrev (next warm start, q(v), posterior)
+    //     and the last workgroup of the final reduction wrote results + diagnostics into the pinned host block
     return VGGP_OK;
 }
 
@@ -514,7 +513,7 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{nullptr, payload, yy_total};
     rc = run_graph(c, warm ? VG_G_FINISH_WARM : VG_G_FINISH_COLD, key, st,
-                   [&] { return finish_enqueue(c, payload, yy_total, warm, st); });
+                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true); });
     if (rc) return rc;
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
@@ -532,7 +531,7 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     const VgGraphKey key{Y, c->payload, yy_total};
     rc = run_graph(c, warm ? VG_G_STEP_WARM : VG_G_STEP_COLD, key, st, [&] {
         const int r1 = vg_partials_enqueue(c, Y, c->payload, st);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false);
     });
     if (rc) return rc;
     c->have_partials = true;

@@ -83,8 +83,12 @@ struct VgFactorJob {
     double ell_imm;
     int flags;            // VGGP_FLAG_*
 };
-hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const double* theta_dev,
-                                  hipStream_t st);
+struct VgClearArgs;
+// theta may be a device pointer or device-visible pinned host memory; when theta_copy is given the kernel also copies the
+// 5 hyper-parameters there (for the later kernels of the step) and block 0 zeroes the words listed in clr -- this makes
+// the factor build the FIRST node of the step graph (no H2D memcpy node, no separate clear launch).
+hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const double* theta_dev, hipStream_t st,
+                                  double* theta_copy = nullptr, const VgClearArgs* clr = nullptr);
 
 // ---- Cholesky + explicit inverse (chol.hip) ------------------------------------
 struct VgCholJob {
@@ -117,13 +121,20 @@ struct VgEigJob {
     long log_bytes;       // size of the rotlog buffer in bytes (vg_eigh_log_bytes(m))
     int block;            // 1: block-Jacobi variant (m <= 128), 0: scalar cyclic Jacobi
     double tol = 0.0;     // off-diagonal threshold relative to ||G||_F / m (0: VG_EIG_TOL)
-    int fast_switch = 128; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's rounds rotate; 0 = off
+    double* Qt2 = nullptr; // optional second copy of Qt (next step's warm-start basis; may alias Qt0)
+    int fast_switch = 192; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
 };
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);
 hipError_t vg_eigh_setup();
 
 // ---- m-space elementwise / reductions (mspace.hip) -----------------------------
+struct VgHostOut {          // pinned readback block
+    double out[8];
+    double jitter[2];
+    int counters[2][4];
+    int status[2];
+};
 struct VgMspace {
     // inputs
     const double* theta;     // device [5]
@@ -154,6 +165,13 @@ struct VgMspace {
     int m1, m2;
     double n_total;
     double yy;
+    // fused tail: the last workgroup of vg_partial_kernel (ticket) does the final combination and writes results and
+    // diagnostics straight into the pinned host block (no D2H memcpy nodes in the step graph)
+    int* ticket = nullptr;           // device int, zero between launches
+    VgHostOut* hout = nullptr;       // device-visible address of the pinned readback block (may be null)
+    const double* jit[2] = {nullptr, nullptr};
+    const int* status[2] = {nullptr, nullptr};
+    const int* counters[2] = {nullptr, nullptr};
 };
 hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st);
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st);

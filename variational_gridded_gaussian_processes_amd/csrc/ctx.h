@@ -23,12 +23,7 @@ struct VgGraphKey {
     bool operator==(const VgGraphKey& o) const { return y == o.y && payload == o.payload && yy == o.yy; }
 };
 
-struct HostOut {            // pinned readback block
-    double out[8];
-    double jitter[2];
-    int counters[2][4];
-    int status[2];
-};
+typedef VgHostOut HostOut;   // pinned readback block (common.h)
 
 struct vggp_ctx {
     int device = 0;
@@ -49,6 +44,9 @@ struct vggp_ctx {
     // pinned host staging
     double* h_theta = nullptr;
     HostOut* h_out = nullptr;
+    HostOut* d_hout = nullptr;       // device-visible address of h_out
+    double* d_htheta = nullptr;      // device-visible address of h_theta
+    int* ticket = nullptr;           // last-block ticket of the fused final reduction
     // scratch for the exported building blocks / posterior (lazy)
     void* misc = nullptr;
     size_t misc_bytes = 0;

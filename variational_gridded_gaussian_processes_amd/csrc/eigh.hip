@@ -223,9 +223,9 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
 #ifdef VG_EIG_STAMP
     unsigned long long fU = 0, fA = 0, fB = 0, fN = 0, fs0, fs1;
 #endif
-    const int switch_below = (n1 * J.fast_switch) >> 8;     // continue here while >= this many rounds of a sweep rotate
+    const int switch_below = (half * n1 * J.fast_switch) >> 8;     // continue here while >= this many PAIRS of a sweep rotate
     for (; sweeps < VG_EIG_MAXSWEEP && !status;) {
-        int active_rounds = 0;
+        int active_rounds = 0, rotations = 0;
         for (int r = 0; r < n1; ++r, ++R) {
             const int cur = R & 1;
 #ifdef VG_EIG_STAMP
@@ -254,6 +254,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
                 }
                 ++nlog;
                 ++active_rounds;
+                rotations += na;
             }
             if (desig) dst[wE] = eprime;               // in-pair element after this round's rotation (0, or untouched)
             double out0 = 0.0, out1 = 0.0, out2 = 0.0, out3 = 0.0;
@@ -297,7 +298,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
         if (status) break;
         ++sweeps;
         if (active_rounds == 0) { converged = true; break; }
-        if (active_rounds < switch_below) break;
+        if (rotations < switch_below) break;
         if (sweeps >= VG_EIG_MAXSWEEP) status = VGGP_ENOCONV;
     }
     // ---- epilogue: identity layout again (R is a multiple of n1); restore the diagonal, drain the log wave ----
@@ -373,10 +374,17 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
 #ifdef VG_EIG_STAMP
     unsigned long long tP = 0, tB1 = 0, tU = 0, tB2 = 0, t0s, t1s;
 #endif
-    for (int sweep = sweeps; sweep < VG_EIG_MAXSWEEP && !converged && !status; ++sweep) {
+    // ---- moving-index rounds: the matrix stays in place, pair k of round r is vg_pair(m2, r, k).  Cost follows the number
+    // of pairs that actually rotate: the angle lanes also finish their own diagonal block and compact the rotating pairs
+    // into a list; the update then visits only the blocks (a, b) of listed pairs a -- one wave per listed pair, one lane
+    // per partner pair b -- so a round with a handful of rotations (the late sweeps of a warm start: hundreds of rounds
+    // with 1-4 rotations each) costs a few hundred cycles, and a round with none costs one barrier.
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    int rr = 0;                                    // running round count: the two counters alternate across sweep
+    for (int sweep = sweeps; sweep < VG_EIG_MAXSWEEP && !converged && !status; ++sweep) {      // boundaries too (m2 - 1 is odd)
         bool any = false;
-        for (int r = 0; r < m2 - 1; ++r) {
-            const int par = r & 1;
+        for (int r = 0; r < m2 - 1; ++r, ++rr) {
+            const int par = rr & 1;
 #ifdef VG_EIG_STAMP
             VG_STAMP(t0s);
 #endif
@@ -384,23 +392,18 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
                 int p, q;
                 vg_pair(m2, r, tid, p, q);
                 const int tp = vg_tri(p), tq = vg_tri(q);
-                const double gpp = W[tp + p], gqq = W[tq + q], gpq = W[vg_symo(p, tp, q, tq)];
+                const int apq = vg_symo(p, tp, q, tq);
+                const double gpq = W[apq];
                 double c = 1.0, s = 0.0;
                 const bool rot = fabs(gpq) > thr;
                 if (rot) {
-                    // t = sign(tau) / (|tau| + sqrt(1 + tau^2)), tau = (gqq - gpp) / (2 gpq), written without a
-                    // division by the small pivot:  t = 2 gpq sign(d) / (|d| + sqrt(d^2 + 4 gpq^2)),  d = gqq - gpp
-                    const double d = gqq - gpp, o = 2.0 * gpq;
-                    const double ad = fabs(d), ao = fabs(o);
-                    const double big = fmax(ad, ao);
-                    const double ib = vg_rcp(big);
-                    const double dn = ad * ib, on = ao * ib;                       // scaled to avoid over/underflow
-                    const double hyp = (dn * dn + on * on) * vg_rsq(dn * dn + on * on);   // sqrt(dn^2 + on^2)
-                    double t = on * vg_rcp(dn + hyp);
-                    if ((d >= 0.0) != (o >= 0.0)) t = -t;
-                    c = vg_rsq(1.0 + t * t);
-                    s = t * c;
-                    atomicAdd(&nact_s[par], 1);
+                    const double gpp = W[tp + p], gqq = W[tq + q];
+                    const VgAngle a = vg_angle3(gpp, gqq, gpq, thr);
+                    c = a.c; s = a.s;
+                    W[tp + p] = gpp - a.t * gpq;               // the pair's own diagonal block, in closed form
+                    W[tq + q] = gqq + a.t * gpq;
+                    W[apq] = 0.0;
+                    act[atomicAdd(&nact_s[par], 1)] = tid;     // list order is irrelevant: the listed blocks are disjoint
                 }
                 isact[tid] = rot;
                 cs[tid] = make_double2(c, s);
@@ -431,79 +434,18 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
             if (tid == 0) __hip_atomic_store(&J.roundlog[nlog], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++nlog;
             any = true;
-            if (VG_SPARSE_OK && na * 2 <= half) {
-                // sparse round: only blocks in a rotating row or column change.  (a, b) runs over half^2 with a
-                // cheap skip on isact[a] (for half == 64 a wave is exactly one row a, so the skip is wave-uniform);
-                // a block with both pairs rotating is done once, from its larger index.
-                for (int idx = tid; idx < half * half; idx += nthr) {
-                    const int a = idx / half, b = idx - a * half;
-                    if (!isact[a]) continue;
-                    if (a == b) {
-                        vg_block_diag(W, pq[a], cs[a].x, cs[a].y);
-                    } else if (!isact[b] || a > b) {
-                        const int al = a > b ? a : b, be = a > b ? b : a;
-                        vg_block(W, pq[al], cs[al].x, cs[al].y, pq[be], cs[be].x, cs[be].y);
-                    }
-                }
-            } else {
-                // full round: every canonical block (al >= be).  The block -> thread map does not depend on the
-                // round, so it was hoisted (my_al/my_be); all LDS loads of a thread's blocks are issued before any
-                // math (the blocks of one round are disjoint, the compiler cannot know that).
-                if (!INLDS) {
-                    for (int al = ty; al < half; al += nty) {
-                        const VgPairRec A = pq[al];
-                        const double ca = cs[al].x, sa = cs[al].y;
-                        for (int be = tx; be <= al; be += 32) {
-                            if (be == al) vg_block_diag(W, A, ca, sa);
-                            else vg_block(W, A, ca, sa, pq[be], cs[be].x, cs[be].y);
-                        }
-                    }
-                } else
-#pragma unroll
-                for (int base = 0; base < VG_MAXMINE; base += VG_UB) {
-                    if (base >= nmine) break;
-                    VgPairRec RA[VG_UB], RB[VG_UB];
-                    double2 CA[VG_UB], CB[VG_UB];
-                    int ad[VG_UB][4];
-                    double g[VG_UB][4];
-                    bool ok[VG_UB], dg[VG_UB];
-#pragma unroll
-                    for (int u = 0; u < VG_UB; ++u) {
-                        ok[u] = base + u < nmine;
-                        const int al = ok[u] ? my_al[base + u] : 0, be = ok[u] ? my_be[base + u] : 0;
-                        dg[u] = al == be;
-                        RA[u] = pq[al]; CA[u] = cs[al];
-                        RB[u] = pq[be]; CB[u] = cs[be];
-                    }
-#pragma unroll
-                    for (int u = 0; u < VG_UB; ++u) {
-                        ad[u][0] = vg_symo(RA[u].p, RA[u].tp, RB[u].p, RB[u].tp);
-                        ad[u][1] = vg_symo(RA[u].p, RA[u].tp, RB[u].q, RB[u].tq);
-                        ad[u][2] = vg_symo(RA[u].q, RA[u].tq, RB[u].p, RB[u].tp);
-                        ad[u][3] = vg_symo(RA[u].q, RA[u].tq, RB[u].q, RB[u].tq);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[u][e] = W[ad[u][e]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < VG_UB; ++u) {
-                        if (!ok[u]) continue;
-                        const double ca = CA[u].x, sa = CA[u].y, cb = CB[u].x, sb = CB[u].y;
-                        if (dg[u]) {
-                            // diagonal block: g[0]=gpp, g[1]=g[2]=gpq, g[3]=gqq
-                            const double gpp = g[u][0], gpq = g[u][1], gqq = g[u][3];
-                            const double cc = ca * ca, ss = sa * sa, cs2 = 2.0 * ca * sa * gpq;
-                            W[ad[u][0]] = cc * gpp - cs2 + ss * gqq;
-                            W[ad[u][3]] = ss * gpp + cs2 + cc * gqq;
-                            W[ad[u][1]] = (cc - ss) * gpq + ca * sa * (gpp - gqq);
-                        } else {
-                            const double h00 = cb * g[u][0] - sb * g[u][1], h01 = sb * g[u][0] + cb * g[u][1];
-                            const double h10 = cb * g[u][2] - sb * g[u][3], h11 = sb * g[u][2] + cb * g[u][3];
-                            W[ad[u][0]] = ca * h00 - sa * h10;
-                            W[ad[u][2]] = sa * h00 + ca * h10;
-                            W[ad[u][1]] = ca * h01 - sa * h11;
-                            W[ad[u][3]] = sa * h01 + ca * h11;
-                        }
-                    }
+            for (int sidx = wave; sidx < na; sidx += nwave) {
+                const int a = act[sidx];                                  // wave-uniform
+                const VgPairRec A = pq[a];
+                const double2 ra = cs[a];
+                for (int b = lane; b < half; b += 64) {
+                    if (b == a) continue;                                 // diagonal block: done by the angle lane
+                    const bool both = isact[b];
+                    if (both && a < b) continue;                          // the larger listed index does the shared block
+                    const double2 rb = both ? cs[b] : make_double2(1.0, 0.0);
+                    // vg_block wants (row pair, column pair) in canonical order al > be
+                    if (a > b) vg_block(W, A, ra.x, ra.y, pq[b], rb.x, rb.y);
+                    else vg_block(W, pq[b], rb.x, rb.y, A, ra.x, ra.y);
                 }
             }
 #ifdef VG_EIG_STAMP
@@ -634,7 +576,11 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
     __syncthreads();
     for (int idx = tid; idx < m * VG_RP_COLS; idx += nthr) {
         const int i = idx >> csh, j = j0 + (idx & (VG_RP_COLS - 1));
-        if (j < m) J.Qt[i * m + j] = T[i * VG_RP_LD + (idx & (VG_RP_COLS - 1))];
+        if (j < m) {
+            const double v = T[i * VG_RP_LD + (idx & (VG_RP_COLS - 1))];
+            J.Qt[i * m + j] = v;
+            if (J.Qt2) J.Qt2[i * m + j] = v;
+        }
     }
 }
 
@@ -1082,7 +1028,11 @@ __device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int*
     __syncthreads();
     for (int idx = tid; idx < m * 16; idx += nthr) {
         const int i = idx >> 4, j = j0 + (idx & 15);
-        if (j < m) J.Qt[i * m + j] = T[i * 17 + (idx & 15)];
+        if (j < m) {
+            const double v = T[i * 17 + (idx & 15)];
+            J.Qt[i * m + j] = v;
+            if (J.Qt2) J.Qt2[i * m + j] = v;
+        }
     }
 }
 

@@ -98,8 +98,14 @@ __device__ __forceinline__ void vg_b0_K_f32(int kd, double delta, double ell, do
     dv = 2.0 * ell * r + ell * ell * dr;
 }
 
-__global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs args, const double* __restrict__ theta) {
+__global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs args, const double* __restrict__ theta,
+                                                       double* theta_copy, const VgClearArgs clr) {
     const int bid = blockIdx.x;
+    if (bid == 0) {                                  // step prologue duties (see vg_factor_build_launch)
+        if (theta_copy && threadIdx.x < 5) theta_copy[threadIdx.x] = theta[threadIdx.x];
+        for (int k = 0; k < clr.n; ++k)
+            for (int i = threadIdx.x; i < clr.nwords[k]; i += 256) clr.ptr[k][i] = 0;
+    }
     int part = 0;
     for (int i = 1; i < 2 * args.njobs; ++i)
         if (bid >= args.block_start[i]) part = i;
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs args,
     }
 }
 
-hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const double* theta_dev, hipStream_t st) {
+hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const double* theta_dev, hipStream_t st,
+                                  double* theta_copy, const VgClearArgs* clr) {
     if (njobs < 1 || njobs > VG_FB_MAXJOBS) return hipErrorInvalidValue;
     VgFactorArgs a;
     a.njobs = njobs;
@@ -154,6 +161,8 @@ hipError_t vg_factor_build_launch(const VgFactorJob* jobs, int njobs, const doub
     }
     a.block_start[2 * njobs] = blocks;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(vg_factor_kernel, dim3(blocks), dim3(256), 0, st, a, theta_dev);
+    VgClearArgs c0;
+    c0.n = 0;
+    hipLaunchKernelGGL(vg_factor_kernel, dim3(blocks), dim3(256), 0, st, a, theta_dev, theta_copy, clr ? *clr : c0);
     return hipGetLastError();
 }

@@ -74,125 +74,132 @@ hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---- final reduction in two launches -----------------------------------------------------------------------------
-// (1) vg_partial_kernel, VG_NPART workgroups: column sums of 1/D and lam1/D, and slices of the four m x m dot
-//     products sum(E o X), sum(F o Xl) per dimension;  (2) vg_final_kernel, one workgroup: O(m) combinations only.
+// ---- final reduction: ONE launch ------------------------------------------------------------------------------------
+// VG_NPART workgroups compute the column sums of 1/D and lam1/D and slices of the four m x m dot products sum(E o X),
+// sum(F o Xl); the workgroup that draws the last ticket then does the O(m) combinations (all partial sums of all
+// workgroups are visible to it: release fence before the ticket, acquire after) and writes the 6 results plus the step's
+// diagnostics (jitter levels, status words, Jacobi counters) straight into the pinned host block.
 #define VG_NPART 64
+#define VG_NFIN 23          // scalars the final combination needs
 
-__global__ __launch_bounds__(256) void vg_partial_kernel(const VgMspace ms) {
-    __shared__ double red[16];
-    const int m1 = ms.m1, m2 = ms.m2, b = blockIdx.x;
-    const double s1 = ms.theta[2];
-    // column sums: block b owns columns b, b + VG_NPART, ...
-    for (int i2 = b; i2 < m2; i2 += VG_NPART) {
-        double a = 0.0, c = 0.0;
-        for (int i1 = threadIdx.x; i1 < m1; i1 += blockDim.x) {
-            const double iD = ms.invD[(long)i1 * m2 + i2];
-            a += iD;
-            c += s1 * ms.lam1[i1] * iD;
-        }
-        a = vg_block_sum(a, red);
-        c = vg_block_sum(c, red);
-        if (threadIdx.x == 0) { ms.r2[i2] = a; ms.r2l[i2] = c; }
+// sums NV values per thread over the workgroup in one pass (wave shuffles, then one LDS stage); result in every thread
+template <int NV>
+__device__ __forceinline__ void vg_block_sum_n(double (&v)[NV], double* red /* >= 4 * NV */) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = vg_wave_sum(v[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[(threadIdx.x >> 6) * NV + q] = v[q];
     }
-    // dot-product slices
-    double ex1 = 0, fx1 = 0, ex2 = 0, fx2 = 0;
-    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m1 * m1; idx += (long)VG_NPART * blockDim.x) {
-        ex1 += ms.E1[idx] * ms.X1[idx];
-        fx1 += ms.F1[idx] * ms.X1l[idx];
-    }
-    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m2 * m2; idx += (long)VG_NPART * blockDim.x) {
-        ex2 += ms.E2[idx] * ms.X2[idx];
-        fx2 += ms.F2[idx] * ms.X2l[idx];
-    }
-    ex1 = vg_block_sum(ex1, red); fx1 = vg_block_sum(fx1, red);
-    ex2 = vg_block_sum(ex2, red); fx2 = vg_block_sum(fx2, red);
-    if (threadIdx.x == 0) {
-        ms.dotpart[b * 4 + 0] = ex1; ms.dotpart[b * 4 + 1] = fx1;
-        ms.dotpart[b * 4 + 2] = ex2; ms.dotpart[b * 4 + 3] = fx2;
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += red[w * NV + q];
+        v[q] = t;
     }
 }
 
-struct VgDimSums { double se, ser, sfr, sf, sel; };
-
-__device__ VgDimSums vg_dim_sums(const double* E, const double* F, const double* lam0, double s, const double* r,
-                                 const double* rl, int m, double* red) {
-    VgDimSums o;
-    double se = 0, ser = 0, sfr = 0, sf = 0, sel = 0;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const double e = E[(long)i * m + i], f = 2.0 * s * F[(long)i * m + i];
-        se += e;
-        ser += e * r[i];
-        sfr += f * rl[i];
-        sf += f;
-        sel += e * s * lam0[i];
-    }
-    o.se = vg_block_sum(se, red);
-    o.ser = vg_block_sum(ser, red);
-    o.sfr = vg_block_sum(sfr, red);
-    o.sf = vg_block_sum(sf, red);
-    o.sel = vg_block_sum(sel, red);
-    return o;
-}
-
-__global__ __launch_bounds__(256) void vg_final_kernel(const VgMspace ms) {
-    __shared__ double red[16];
+__device__ void vg_final_body(const VgMspace& ms, double* red) {
     const int m1 = ms.m1, m2 = ms.m2;
     const double s1 = ms.theta[2], s2 = ms.theta[3], v = ms.theta[4];
     const double N = ms.n_total, yy = ms.yy;
-
-    double S[7];
+    // S[0..6]: row partials; [7..10]: dot products; [11],[12]: sum lam; [13..17]: dimension 1 sums; [18..22]: dimension 2
+    double S[VG_NFIN];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-        double t = 0.0;
-        for (int i = threadIdx.x; i < m1; i += blockDim.x) t += ms.rowpart[i * 8 + q];
-        S[q] = vg_block_sum(t, red);
-    }
-    double dp[4];
+    for (int q = 0; q < VG_NFIN; ++q) S[q] = 0.0;
+    for (int i = threadIdx.x; i < m1; i += blockDim.x) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        double t = 0.0;
-        for (int i = threadIdx.x; i < VG_NPART; i += blockDim.x) t += ms.dotpart[i * 4 + q];
-        dp[q] = vg_block_sum(t, red);
+        for (int q = 0; q < 7; ++q) S[q] += ms.rowpart[i * 8 + q];
+        S[11] += ms.lam1[i];
+        const double e = ms.E1[(long)i * m1 + i], f = 2.0 * s1 * ms.F1[(long)i * m1 + i];
+        S[13] += e; S[14] += e * ms.r1[i]; S[15] += f * ms.r1l[i]; S[16] += f; S[17] += e * s1 * ms.lam1[i];
     }
-    double t1 = 0.0, t2 = 0.0;
-    for (int i = threadIdx.x; i < m1; i += blockDim.x) t1 += ms.lam1[i];
-    for (int i = threadIdx.x; i < m2; i += blockDim.x) t2 += ms.lam2[i];
-    const double sl1 = s1 * vg_block_sum(t1, red), sl2 = s2 * vg_block_sum(t2, red);
-
-    const VgDimSums d1 = vg_dim_sums(ms.E1, ms.F1, ms.lam1, s1, ms.r1, ms.r1l, m1, red);
-    const VgDimSums d2 = vg_dim_sums(ms.E2, ms.F2, ms.lam2, s2, ms.r2, ms.r2l, m2, red);
-    const double EX1 = dp[0], FX1 = 2.0 * s1 * dp[1], EX2 = dp[2], FX2 = 2.0 * s2 * dp[3];
-
+    for (int i = threadIdx.x; i < m2; i += blockDim.x) {
+        S[12] += ms.lam2[i];
+        const double e = ms.E2[(long)i * m2 + i], f = 2.0 * s2 * ms.F2[(long)i * m2 + i];
+        S[18] += e; S[19] += e * ms.r2[i]; S[20] += f * ms.r2l[i]; S[21] += f; S[22] += e * s2 * ms.lam2[i];
+    }
+    for (int i = threadIdx.x; i < VG_NPART; i += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[7 + q] += ms.dotpart[i * 4 + q];
+    }
+    vg_block_sum_n<VG_NFIN>(S, red);
     if (threadIdx.x == 0) {
+        const double sl1 = s1 * S[11], sl2 = s2 * S[12];
+        const double EX1 = S[7], FX1 = 2.0 * s1 * S[8], EX2 = S[9], FX2 = 2.0 * s2 * S[10];
         const double v2 = v * v;
         const double elbo = -0.5 * (N * 1.8378770664093453 + N * log(v) + S[0] + yy / v - S[1] / v2)
                             - (N * s1 * s2 - sl1 * sl2) / (2.0 * v);
         const double quad1 = 2.0 * S[5] - EX1 - FX1 / v;
         const double quad2 = 2.0 * S[6] - EX2 - FX2 / v;
-        const double g_l1 = -0.5 * (d1.ser + d1.sfr / v - (double)m2 * d1.se - quad1 / v2)
-                            + sl2 / (2.0 * v) * (d1.sf - d1.sel);
-        const double g_l2 = -0.5 * (d2.ser + d2.sfr / v - (double)m1 * d2.se - quad2 / v2)
-                            + sl1 / (2.0 * v) * (d2.sf - d2.sel);
+        const double g_l1 = -0.5 * (S[14] + S[15] / v - (double)m2 * S[13] - quad1 / v2) + sl2 / (2.0 * v) * (S[16] - S[17]);
+        const double g_l2 = -0.5 * (S[19] + S[20] / v - (double)m1 * S[18] - quad2 / v2) + sl1 / (2.0 * v) * (S[21] - S[22]);
         const double common = -0.5 * (S[3] - S[2] / v2);
         const double g_s1 = common / s1 + sl1 * sl2 / (2.0 * v * s1) - N * s2 / (2.0 * v);
         const double g_s2 = common / s2 + sl1 * sl2 / (2.0 * v * s2) - N * s1 / (2.0 * v);
-        const double g_v = -0.5 * (N / v - S[3] / v - yy / v2 + S[4] / (v2 * v))
-                           + (N * s1 * s2 - sl1 * sl2) / (2.0 * v2);
-        ms.out[0] = elbo;
-        ms.out[1] = g_l1;
-        ms.out[2] = g_l2;
-        ms.out[3] = g_s1;
-        ms.out[4] = g_s2;
-        ms.out[5] = g_v;
+        const double g_v = -0.5 * (N / v - S[3] / v - yy / v2 + S[4] / (v2 * v)) + (N * s1 * s2 - sl1 * sl2) / (2.0 * v2);
+        const double o[6] = {elbo, g_l1, g_l2, g_s1, g_s2, g_v};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ms.out[q] = o[q];
+        if (ms.hout) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ms.hout->out[q] = o[q];
+            for (int k = 0; k < 2; ++k) {
+                ms.hout->jitter[k] = ms.jit[k] ? *ms.jit[k] : 0.0;
+                ms.hout->status[k] = ms.status[k] ? *ms.status[k] : 0;
+                for (int q = 0; q < 4; ++q) ms.hout->counters[k][q] = ms.counters[k] ? ms.counters[k][q] : 0;
+            }
+        }
     }
 }
 
+__global__ __launch_bounds__(256) void vg_partial_kernel(const VgMspace ms) {
+    __shared__ double red[4 * VG_NFIN];
+    __shared__ int s_last;
+    const int m1 = ms.m1, m2 = ms.m2, b = blockIdx.x;
+    const double s1 = ms.theta[2];
+    // column sums: block b owns columns b, b + VG_NPART, ...
+    for (int i2 = b; i2 < m2; i2 += VG_NPART) {
+        double ac[2] = {0.0, 0.0};
+        for (int i1 = threadIdx.x; i1 < m1; i1 += blockDim.x) {
+            const double iD = ms.invD[(long)i1 * m2 + i2];
+            ac[0] += iD;
+            ac[1] += s1 * ms.lam1[i1] * iD;
+        }
+        vg_block_sum_n<2>(ac, red);
+        if (threadIdx.x == 0) { ms.r2[i2] = ac[0]; ms.r2l[i2] = ac[1]; }
+    }
+    // dot-product slices
+    double dp[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m1 * m1; idx += (long)VG_NPART * blockDim.x) {
+        dp[0] += ms.E1[idx] * ms.X1[idx];
+        dp[1] += ms.F1[idx] * ms.X1l[idx];
+    }
+    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m2 * m2; idx += (long)VG_NPART * blockDim.x) {
+        dp[2] += ms.E2[idx] * ms.X2[idx];
+        dp[3] += ms.F2[idx] * ms.X2l[idx];
+    }
+    vg_block_sum_n<4>(dp, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ms.dotpart[b * 4 + q] = dp[q];
+        __threadfence();                                         // release this workgroup's partial sums ...
+        const int t = atomicAdd(ms.ticket, 1);                   // ... before drawing the ticket
+        s_last = (t == VG_NPART - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                             // acquire: every other workgroup's partial sums
+    if (threadIdx.x == 0) *ms.ticket = 0;                        // self-cleaning for the next launch
+    vg_final_body(ms, red);
+}
+
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st) {
+    if (!ms->ticket) return hipErrorInvalidValue;
     hipLaunchKernelGGL(vg_partial_kernel, dim3(VG_NPART), dim3(256), 0, st, *ms);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(vg_final_kernel, dim3(1), dim3(256), 0, st, *ms);
     return hipGetLastError();
 }
 
