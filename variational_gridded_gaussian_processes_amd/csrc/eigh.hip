@@ -51,6 +51,8 @@ __device__ __forceinline__ int vg_sym(int i, int j) { return i >= j ? vg_tri(i) 
 // per-pair record kept in LDS for the round: indices and their packed-row offsets (no integer multiplies in
 // the update loop: v_mul_lo_u32 is quarter rate), rotation (c, s)
 struct VgPairRec { int p, q, tp, tq; };
+// a rotating pair of the current round, compacted: indices, packed-row offsets, rotation, pair index k
+struct VgActRec { int p, q, tp, tq; double c, s; int k, pad; };
 __device__ __forceinline__ int vg_symo(int i, int ti, int j, int tj) { return i >= j ? ti + j : tj + i; }
 
 // one 2x2 block G[{pa,qa},{pb,qb}] <- Ja^T . Jb, read once / written once at its canonical addresses
@@ -322,7 +324,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
 }
 
 template <bool INLDS>
-__device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, int* act, unsigned char* isact,
+__device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, VgActRec* actrec, unsigned char* isact,
                                int* nact_s, double* red, bool fast) {
     const int m = J.m;
     const int m2 = m + (m & 1), half = m2 >> 1;
@@ -393,23 +395,32 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
                 vg_pair(m2, r, tid, p, q);
                 const int tp = vg_tri(p), tq = vg_tri(q);
                 const int apq = vg_symo(p, tp, q, tq);
-                const double gpq = W[apq];
-                double c = 1.0, s = 0.0;
+                const double gpq = W[apq], gpp = W[tp + p], gqq = W[tq + q];       // one LDS round trip for all three
                 const bool rot = fabs(gpq) > thr;
+                double c = 1.0, s = 0.0;
+                // compaction of the rotating pairs: ballot + prefix count when the angle lanes are one wave (no LDS atomic
+                // on the critical path), LDS counter otherwise.  List order is irrelevant: the listed blocks are disjoint.
+                int slot = 0;
+                if (half <= 64) {
+                    const unsigned long long bal = __ballot(rot);
+                    slot = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                    if (tid == 0) nact_s[par] = __popcll(bal);
+                } else if (rot) {
+                    slot = atomicAdd(&nact_s[par], 1);
+                }
                 if (rot) {
-                    const double gpp = W[tp + p], gqq = W[tq + q];
                     const VgAngle a = vg_angle3(gpp, gqq, gpq, thr);
                     c = a.c; s = a.s;
                     W[tp + p] = gpp - a.t * gpq;               // the pair's own diagonal block, in closed form
                     W[tq + q] = gqq + a.t * gpq;
                     W[apq] = 0.0;
-                    act[atomicAdd(&nact_s[par], 1)] = tid;     // list order is irrelevant: the listed blocks are disjoint
+                    actrec[slot] = VgActRec{p, q, tp, tq, c, s, tid, 0};
                 }
                 isact[tid] = rot;
                 cs[tid] = make_double2(c, s);
                 pq[tid] = VgPairRec{p, q, tp, tq};
             }
-            if (tid == nthr - 1) nact_s[par ^ 1] = 0;
+            if (tid == nthr - 1 && half > 64) nact_s[par ^ 1] = 0;
 #ifdef VG_EIG_STAMP
             VG_STAMP(t1s); tP += t1s - t0s;
 #endif
@@ -435,17 +446,18 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
             ++nlog;
             any = true;
             for (int sidx = wave; sidx < na; sidx += nwave) {
-                const int a = act[sidx];                                  // wave-uniform
-                const VgPairRec A = pq[a];
-                const double2 ra = cs[a];
+                const VgActRec R = actrec[sidx];                          // wave-uniform: pair, offsets, rotation, pair index
+                const int a = R.k;
+                const VgPairRec A{R.p, R.q, R.tp, R.tq};
                 for (int b = lane; b < half; b += 64) {
+                    const bool both = isact[b];                           // these three loads do not depend on R:
+                    const double2 rbv = cs[b];                            // everything the block needs arrives in one
+                    const VgPairRec B = pq[b];                            // LDS round trip
                     if (b == a) continue;                                 // diagonal block: done by the angle lane
-                    const bool both = isact[b];
                     if (both && a < b) continue;                          // the larger listed index does the shared block
-                    const double2 rb = both ? cs[b] : make_double2(1.0, 0.0);
-                    // vg_block wants (row pair, column pair) in canonical order al > be
-                    if (a > b) vg_block(W, A, ra.x, ra.y, pq[b], rb.x, rb.y);
-                    else vg_block(W, pq[b], rb.x, rb.y, A, ra.x, ra.y);
+                    // vg_block wants (row pair, column pair) in canonical order al > be; rbv is the identity if b rests
+                    if (a > b) vg_block(W, A, R.c, R.s, B, rbv.x, rbv.y);
+                    else vg_block(W, B, rbv.x, rbv.y, A, R.c, R.s);
                 }
             }
 #ifdef VG_EIG_STAMP
@@ -1043,7 +1055,7 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     extern __shared__ double vg_eig_dyn[];
     __shared__ double2 cs[512];
     __shared__ VgPairRec pq[512];
-    __shared__ int act[512];
+    __shared__ VgActRec actrec[128];          // rotating pairs of the current round (half <= 128)
     __shared__ unsigned char isact[512];
     __shared__ int nact_s[2];
     __shared__ double red[16];
@@ -1051,8 +1063,8 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     const bool block_mode = J.block && J.m <= VG_BJ_MAX_M;
     if (blockIdx.x == 0) {
         if (block_mode) vg_bjacobi_body(J, vg_eig_dyn, cs, pq, nact_s, red);
-        else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, act, isact, nact_s, red, a.fast[blockIdx.y] != 0);
-        else vg_jacobi_body<false>(J, J.gwork, cs, pq, act, isact, nact_s, red, false);
+        else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, actrec, isact, nact_s, red, a.fast[blockIdx.y] != 0);
+        else vg_jacobi_body<false>(J, J.gwork, cs, pq, actrec, isact, nact_s, red, false);
     } else {
         if (block_mode) vg_breplay_body(J, blockIdx.x - 1, vg_eig_dyn, nact_s);
         else vg_replay_body(J, blockIdx.x - 1, a.rp_cols, vg_eig_dyn, nact_s);
@@ -1072,7 +1084,7 @@ size_t vg_eigh_log_bytes(int m) {
 
 hipError_t vg_eigh_setup() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
 }
 
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid) {
@@ -1110,7 +1122,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
         if (need > lds) lds = need;
         if (m2 > maxm2) maxm2 = m2;
     }
-    if (lds > 140 * 1024) return hipErrorInvalidValue;
+    if (lds > 136 * 1024) return hipErrorInvalidValue;
     const int ncb = (maxm2 + VG_RP_COLS - 1) / VG_RP_COLS;
     hipLaunchKernelGGL(vg_eigh_kernel, dim3(1 + ncb, njobs), dim3(1024), lds, st, a);
     return hipGetLastError();
