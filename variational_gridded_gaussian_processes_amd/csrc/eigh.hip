@@ -50,9 +50,9 @@ __device__ __forceinline__ int vg_sym(int i, int j) { return i >= j ? vg_tri(i) 
 
 // per-pair record kept in LDS for the round: indices and their packed-row offsets (no integer multiplies in
 // the update loop: v_mul_lo_u32 is quarter rate), rotation (c, s)
-struct VgPairRec { int p, q, tp, tq; };
+struct __attribute__((aligned(16))) VgPairRec { int p, q, tp, tq; };
 // a rotating pair of the current round, compacted: indices, packed-row offsets, rotation, pair index k
-struct VgActRec { int p, q, tp, tq; double c, s; int k, pad; };
+struct __attribute__((aligned(16))) VgActRec { int p, q, tp, tq; double c, s; int k, pad; };
 __device__ __forceinline__ int vg_symo(int i, int ti, int j, int tj) { return i >= j ? ti + j : tj + i; }
 
 // one 2x2 block G[{pa,qa},{pb,qb}] <- Ja^T . Jb, read once / written once at its canonical addresses
@@ -165,8 +165,11 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
         const int ngen = (half * (half - 1)) / 2 - half;            // blocks that are not designated
         const int per = nthr - 64;
         int g[2];
-        if (wave == 0) { g[0] = -1; g[1] = 2 * per + lane; }
-        else { g[0] = tid - 64; g[1] = tid - 64 + per; }
+        // waves 1..15: one block from the front of the enumeration (short rows) and its mirror from the back (long rows),
+        // so every wave carries the same mix; wave 0's second half-slot takes the blocks in the middle that remain
+        const int hfront = (ngen + 1) / 2, t = tid - 64;
+        if (wave == 0) { g[0] = -1; g[1] = (per + lane < ngen - per) ? per + lane : -1; }
+        else { g[0] = (t < hfront) ? t : -1; g[1] = (ngen - 1 - t >= hfront) ? ngen - 1 - t : -1; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             int al = 0, be = 0;
@@ -1052,7 +1055,7 @@ __device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int*
 // rotation log on column block blockIdx.x-1 of Q^T while the producer is still running (the replay is ~3x faster
 // per round, so it finishes a few microseconds after the producer).  At most 2*(1+8) workgroups: always co-resident.
 __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
-    extern __shared__ double vg_eig_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double vg_eig_dyn[];   // double2 views of it are read with ds_read_b128
     __shared__ double2 cs[512];
     __shared__ VgPairRec pq[512];
     __shared__ VgActRec actrec[128];          // rotating pairs of the current round (half <= 128)
