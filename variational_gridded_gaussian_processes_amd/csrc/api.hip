@@ -135,7 +135,8 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.X = b.take<double>(m * m);
         d.Mk = b.take<double>(m * m);
         d.GH = b.take<double>(2 * m * m);
-        d.gh_split = pick_split((int)(((m + 63) / 64) * ((m + 63) / 64)), (int)n, 32);
+        static const char* ghe = getenv("VGGP_GH_TARGET");
+        d.gh_split = pick_split((int)(((m + 63) / 64) * ((m + 63) / 64)), (int)n, ghe ? atoi(ghe) : 32);
         d.GHslab = b.take<double>((size_t)d.gh_split * 2 * m * m);
         d.Gw = b.take<double>(m * m);
         d.lam0 = b.take<double>(m);
@@ -157,7 +158,8 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.status = b.take<int>(2);
     }
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
-    c->st_split = pick_split(st_tiles, (int)n2, 256);
+    static const char* ste = getenv("VGGP_ST_TARGET");
+    c->st_split = pick_split(st_tiles, (int)n2, ste ? atoi(ste) : 256);
     c->St = b.take<double>((size_t)c->st_split * 2 * m2 * n1);
     const int cc_tiles = (int)(((2 * m1 + 63) / 64) * ((m2 + 63) / 64));
     c->cc_split = pick_split(cc_tiles, (int)n1, 64);
@@ -251,7 +253,7 @@ extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t
 // ---------------------------------------------------------------------------------
 // Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
 // caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st) {
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce) {
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     VG_MARK(0);
@@ -299,7 +301,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
     }
     vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
-    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_GRAM_PROJECT));
     VG_MARK(4);
     const int st_slabs = g.p[g.nprob - 1].ksplit;
     const int gh_slabs[2] = {g.p[0].ksplit, g.p[2].ksplit};
@@ -315,7 +317,10 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     VG_MARK(5);
     const int cc_slabs = g.p[0].ksplit;
 
-    // 6. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}
+    c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs;
+    // 6. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}.  Skipped inside a fused
+    //    warm step: its consumers (three small GEMMs) then sum the slabs on load, one launch less on the critical path.
+    if (!reduce) { VG_MARK(6); return VGGP_OK; }
     VgRedBatch r;
     vg_red_init(&r);
     vg_red_add(&r, d1.GHslab, d1.GH, 2L * m1 * m1, 2L * m1 * m1, gh_slabs[0]);
@@ -326,15 +331,21 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     return VGGP_OK;
 }
 
-static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta) {
+static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
+                          bool from_slabs = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
-    const double* G0[2] = {d1.GH, payload};
-    const double* H0[2] = {d1.GH + m1 * m1, payload + m2 * m2};
-    const double* C3 = payload + 2 * m2 * m2;
+    // from_slabs (fused warm step): G, H, C are still split-K slabs; every consumer below is a GEMM that sums them on load
+    const double* G0[2] = {from_slabs ? d1.GHslab : d1.GH, from_slabs ? d2.GHslab : payload};
+    const double* H0[2] = {G0[0] + m1 * m1, G0[1] + m2 * m2};
+    const double* C3 = from_slabs ? c->CCslab : payload + 2 * m2 * m2;
+    const int ghn[2] = {from_slabs ? c->gh_slabs[0] : 1, from_slabs ? c->gh_slabs[1] : 1};
+    const long ghs[2] = {2L * m1 * m1, 2L * m2 * m2};
+    const int ccn = from_slabs ? c->cc_slabs : 1;
+    const long ccs = 3L * m1 * m2;
     VgGemmBatch g;
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
@@ -344,7 +355,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);
@@ -371,9 +382,11 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         vg_gemm_add(&g, d.Mk, d.m, 1, d.Qt, 1, d.m, d.TM, d.m, d.m, d.m, d.m);      // Mk Q
-        vg_gemm_add(&g, H0[k], d.m, 1, d.Qt, 1, d.m, d.TH, d.m, d.m, d.m, d.m);     // H0 Q
+        const int ih = vg_gemm_add(&g, H0[k], d.m, 1, d.Qt, 1, d.m, d.TH, d.m, d.m, d.m, d.m);     // H0 Q
+        g.p[ih].a_nslab = ghn[k]; g.p[ih].a_slab = ghs[k];
     }
-    vg_gemm_add(&g, C3, m2, 1, d2.Qt, 1, m2, c->T3, (int)m2, (int)(3 * m1), (int)m2, (int)m2);   // [C;C1;C2] Q2
+    const int ic = vg_gemm_add(&g, C3, m2, 1, d2.Qt, 1, m2, c->T3, (int)m2, (int)(3 * m1), (int)m2, (int)m2);   // [C;C1;C2] Q2
+    g.p[ic].a_nslab = ccn; g.p[ic].a_slab = ccs;
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(10);
     //    ... then the left factors
@@ -530,8 +543,8 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{Y, c->payload, yy_total};
     rc = run_graph(c, warm ? VG_G_STEP_WARM : VG_G_STEP_COLD, key, st, [&] {
-        const int r1 = vg_partials_enqueue(c, Y, c->payload, st);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false);
+        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm);
     });
     if (rc) return rc;
     c->have_partials = true;

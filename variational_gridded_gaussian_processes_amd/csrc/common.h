@@ -38,6 +38,8 @@ struct VgGemmP {
     long sa_m, sa_k, sb_k, sb_n;
     long c_slab;       // doubles between split-K output slabs
     long b_slab;       // B operand = sum of b_nslab slabs, this many doubles apart
+    long a_slab;       // A operand likewise (a_nslab slabs)
+    int a_nslab;
     int M, N, K;
     int ldc;
     int ksplit;        // >= 1
@@ -60,7 +62,8 @@ void vg_gemm_init(VgGemmBatch* b);
 int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const double* B, long sb_k,
                 long sb_n, double* C, int ldc, int M, int N, int K, int ksplit = 1, long c_slab = 0,
                 int b_nslab = 1, long b_slab = 0, double alpha = 1.0, int accum = 0);
-hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st);
+#define VG_GEMM_TAG_GRAM_PROJECT 1
+hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag = 0);
 
 // segment reduction: out[i] = sum_s in[s*slab + i]
 #define VG_RED_MAXSEG 8

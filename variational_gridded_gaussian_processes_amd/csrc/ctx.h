@@ -38,6 +38,7 @@ struct vggp_ctx {
     double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
     double *out = nullptr, *theta = nullptr, *wq = nullptr;
     int st_split = 1, cc_split = 1;
+    int gh_slabs[2] = {1, 1}, cc_slabs = 1;      // split-K slab counts actually produced by the last partials launch
     long payload_len = 0;
     bool have_partials = false, have_step = false, have_masked = false;
     void* masked = nullptr;          // VgMasked workspace (masked.hip), allocated on first use
@@ -69,5 +70,5 @@ struct vggp_ctx {
 
 
 int vg_ensure_misc(vggp_ctx* c, size_t bytes);
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st);
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true);
 void vg_masked_free(vggp_ctx* c);

@@ -64,8 +64,8 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
     const bool a_kc = (sa_k == 1);   // A is K-contiguous
     const bool b_nc = (sb_n == 1);   // B is N-contiguous
     const int M = p.M, N = p.N;
-    const int nslab = p.b_nslab;
-    const long bslab = p.b_slab;
+    const int nslab = p.b_nslab, anslab = p.a_nslab;
+    const long bslab = p.b_slab, aslab = p.a_slab;
 
     // global->register mapping for the T x BK A tile and BK x T B tile: 4 elements each
     int a_i[4], a_k[4], b_k[4], b_j[4];
@@ -79,14 +79,19 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
     const int a_si = a_kc ? C_::RS : 1, a_sk = a_kc ? 1 : C_::KS;
     const int b_sj = b_nc ? 1 : C_::RS, b_sk = b_nc ? C_::KS : 1;
 
-    double ra[4], rb[4];
-    auto load_tile = [&](int k0) {
+    // two register stages: while tile i is multiplied, tiles i+1 AND i+2 are in flight (one k-tile of MFMAs is ~0.5 us,
+    // an L2 / HBM round trip is 1-2 us: a single stage leaves every k-tile waiting for its operands)
+    double ra0[4], rb0[4], ra1[4], rb1[4];
+    auto load_tile = [&](int k0, double (&ra)[4], double (&rb)[4]) {
         const double* bp[4];
-        bool bok[4];
+        const double* ap[4];
+        bool bok[4], aok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gi = row0 + a_i[r], gk = k0 + a_k[r];
-            ra[r] = (gi < M && gk < k_end) ? A[gi * sa_m + gk * sa_k] : 0.0;
+            aok[r] = gi < M && gk < k_end;
+            ap[r] = A + (aok[r] ? gi * sa_m + gk * sa_k : 0);
+            ra[r] = aok[r] ? ap[r][0] : 0.0;
             const int gj = col0 + b_j[r], gkb = k0 + b_k[r];
             bok[r] = gj < N && gkb < k_end;
             bp[r] = B + (bok[r] ? gkb * sb_k + gj * sb_n : 0);
@@ -103,6 +108,15 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) rb[r] += (t[0][r] + t[1][r]) + t[2][r];
         }
+        for (int s = 1; s < anslab; s += 3) {
+            double t[3][4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[u][r] = (aok[r] && s + u < anslab) ? ap[r][(long)(s + u) * aslab] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ra[r] += (t[0][r] + t[1][r]) + t[2][r];
+        }
     };
 
     vg_d4 acc[MB][MB];
@@ -113,15 +127,14 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
 
     const int fi = lane & 15, fk = lane >> 4;
     constexpr int WT = T / 2;                                  // rows / cols per wave
-    if (k_begin < k_end) load_tile(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    auto ktile = [&](double (&ra)[4], double (&rb)[4], int knext) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             As[a_i[r] * a_si + a_k[r] * a_sk] = ra[r];
             Bs[b_k[r] * b_sk + b_j[r] * b_sj] = rb[r];
         }
         __syncthreads();
-        if (k0 + BK < k_end) load_tile(k0 + BK);   // in flight while the MFMAs run
+        if (knext < k_end) load_tile(knext, ra, rb);           // refill this stage: two k-tiles ahead
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             double av[MB], bv[MB];
@@ -138,6 +151,12 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
                     acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
         }
         __syncthreads();
+    };
+    if (k_begin < k_end) load_tile(k_begin, ra0, rb0);
+    if (k_begin + BK < k_end) load_tile(k_begin + BK, ra1, rb1);
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+        ktile(ra0, rb0, k0 + 2 * BK);
+        if (k0 + BK < k_end) ktile(ra1, rb1, k0 + 3 * BK);
     }
 
     double* __restrict__ C = p.C + (long)ks * p.c_slab;
@@ -159,6 +178,12 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
 }
 
 __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
+    __shared__ double lds[2 * VgTile<64, 16>::TILE];
+    vg_gemm_body<64, 16>(b, lds);
+}
+// the launch that makes the only pass over Y ([G;H] = [B;V] B^T for both dimensions and S = [B2;V2] Y): same body under
+// its own name so that profiler summaries list the step's N-proportional kernel separately from the other GEMM launches
+__global__ __launch_bounds__(256) void vg_gemm_gram_project_kernel(const VgGemmBatch b) {
     __shared__ double lds[2 * VgTile<64, 16>::TILE];
     vg_gemm_body<64, 16>(b, lds);
 }
@@ -192,6 +217,8 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     p.c_slab = c_slab;
     p.b_nslab = b_nslab < 1 ? 1 : b_nslab;
     p.b_slab = b_slab;
+    p.a_nslab = 1;
+    p.a_slab = 0;
     p.tiles_m = (M + VG_BM - 1) / VG_BM;
     p.tiles_n = (N + VG_BN - 1) / VG_BN;
     p.tile_start = b->total_tiles;
@@ -199,7 +226,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     return b->nprob++;
 }
 
-hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st) {
+hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
     if (b->nprob == 0 || b->total_tiles == 0) return hipSuccess;
     // a batch that cannot fill half the chip with 64 x 64 tiles and is not split-K (the m x m x m chain products) runs
     // with 32 x 32 tiles: 4x the workgroups, each with a quarter of the MFMA work per k-tile
@@ -219,7 +246,10 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st) {
         hipLaunchKernelGGL(vg_gemm_small_kernel, dim3(s.total_tiles), dim3(256), 0, st, s);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(vg_gemm_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
+    if (tag == VG_GEMM_TAG_GRAM_PROJECT)
+        hipLaunchKernelGGL(vg_gemm_gram_project_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
+    else
+        hipLaunchKernelGGL(vg_gemm_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
     return hipGetLastError();
 }
 
