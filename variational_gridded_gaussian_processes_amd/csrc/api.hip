@@ -155,6 +155,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.rotlog = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
         d.roundlog = b.take<int>(d.max_rounds);
         d.counters = b.take<int>(4);
+        d.perm = b.take<int>(m2e);
         d.status = b.take<int>(2);
     }
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
@@ -372,6 +373,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
                          d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
                          (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
         ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
+        ej[k].perm = d.perm;
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -730,7 +732,7 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     const long m2e = m + (m & 1);
     const int max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
     const size_t logb = (vg_eigh_log_bytes((int)m) + 15) & ~size_t(15);
-    const size_t need = (size_t)m2e * (m2e + 1) * 8 + logb + (size_t)max_rounds * 4 + 256;
+    const size_t need = (size_t)m2e * (m2e + 1) * 8 + logb + (size_t)max_rounds * 4 + 256 + (size_t)m2e * 4 + 64;
     int rc = vg_ensure_misc(c, need);
     if (rc) return rc;
     char* p = (char*)c->misc;
@@ -739,12 +741,14 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     int* roundlog = (int*)p; p += (size_t)max_rounds * 4;
     p = (char*)(((uintptr_t)p + 63) & ~uintptr_t(63));
     int* counters = (int*)p;
+    int* perm = counters + 16;
     VgClearArgs clr;
     clr.n = 1;
     clr.ptr[0] = counters; clr.nwords[0] = 4;
     VG_HIP(vg_clear_launch(&clr, st));
     VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds, (long)logb,
                (flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
+    j.perm = perm;
     VG_HIP(vg_eigh_launch(&j, 1, st));
     int hc[4] = {0, 0, 0, 0};
     VG_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));

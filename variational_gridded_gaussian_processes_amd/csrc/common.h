@@ -125,6 +125,7 @@ struct VgEigJob {
     int block;            // 1: block-Jacobi variant (m <= 128), 0: scalar cyclic Jacobi
     double tol = 0.0;     // off-diagonal threshold relative to ||G||_F / m (0: VG_EIG_TOL)
     double* Qt2 = nullptr; // optional second copy of Qt (next step's warm-start basis; may alias Qt0)
+    int* perm = nullptr;   // [m] scratch: rank of eigenpair i in decreasing order (scalar variant; null = leave unsorted)
     int fast_switch = 112; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
 };
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)

@@ -11,7 +11,7 @@ struct VgDim {
     double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
     double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
     double2* rotlog = nullptr;
-    int *roundlog = nullptr, *counters = nullptr, *status = nullptr;
+    int *roundlog = nullptr, *counters = nullptr, *status = nullptr, *perm = nullptr;
     int gh_split = 1, max_rounds = 0;
     bool have_prev = false;
 };
