@@ -83,7 +83,7 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
 extern "C" int vggp_destroy(vggp_ctx* c) {
     if (!c) return VGGP_OK;
     (void)hipSetDevice(c->device);
-    for (int i = 0; i < 5; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    for (int i = 0; i < 8; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
     vg_masked_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->arena) (void)hipFree(c->arena);
@@ -142,6 +142,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.lam0 = b.take<double>(m);
         d.Qt = b.take<double>(m * m);
         d.QtPrev = b.take<double>(m * m);
+        d.QtPrev2 = b.take<double>(m * m);
         d.TM = b.take<double>(m * m);
         d.TH = b.take<double>(m * m);
         d.E = b.take<double>(m * m);
@@ -212,6 +213,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     VG_REQUIRE(desc->n1 < (1L << 24) && desc->n2 < (1L << 24), "vggp_plan: grid axis too long");
     c->planned = false;
     graphs_clear(c);
+    c->warm_run = 0;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -254,7 +256,7 @@ extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t
 // ---------------------------------------------------------------------------------
 // Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
 // caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce) {
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap) {
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     VG_MARK(0);
@@ -291,6 +293,17 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
             vg_gemm_add(&g, d.Linv0, d.m, 1, d.AD + b * mn, d.n, 1, d.BV + b * mn, d.n, d.m, d.n, d.m);
         vg_gemm_add(&g, d.Linv0, d.m, 1, d.dK0, d.m, 1, d.X, d.m, d.m, d.m, d.m);
     }
+    // extrapolated warm start (rides in this and the next launch, no launch of its own): the basis moved from Q(t-2) to
+    // Q(t-1) by the rotation Q(t-1) Q(t-2)^T; applying it once more predicts this step's basis,
+    //     Qpred = Q(t-1) Q(t-2)^T Q(t-1)          (rows = eigenvectors; U -> TH, Qpred -> E, all free until after eigh)
+    // A product of three bases triples their departure from orthogonality and feeds it back into the next bases -- it
+    // would grow ~2.4x per step -- so one Newton-Schulz step follows: Q' = 1.5 Qpred - 0.5 (Qpred Qpred^T) Qpred
+    // (1.5 Qpred -> F here, W = Qpred Qpred^T -> TH in the next launch, the last product at the start of the finish).
+    if (extrap)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.TH, d.m, d.m, d.m, d.m);
+        }
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(3);
 
@@ -302,9 +315,15 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
     }
     vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
+    if (extrap)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.TH, d.m, 1, d.QtPrev, d.m, 1, d.E, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.TH, d.m, 1, d.QtPrev, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 1.5, 0);
+        }
     VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_GRAM_PROJECT));
     VG_MARK(4);
-    const int st_slabs = g.p[g.nprob - 1].ksplit;
+    const int st_slabs = g.p[4].ksplit;
     const int gh_slabs[2] = {g.p[0].ksplit, g.p[2].ksplit};
 
     // 5. [C;C1] = [B1;V1] S_B,  C2 = B1 S_V   (S^T slabs summed on load; split-K over n1)
@@ -314,6 +333,11 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
                 st_slabs, 2L * m2 * n1);
     vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
                 c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
+    if (extrap)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.E, d.m, 1, d.E, 1, d.m, d.TH, d.m, d.m, d.m, d.m);      // W = Qpred Qpred^T
+        }
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(5);
     const int cc_slabs = g.p[0].ksplit;
@@ -333,7 +357,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
 }
 
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
-                          bool from_slabs = false) {
+                          bool from_slabs = false, bool extrap = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -352,28 +376,37 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
     VgEigJob ej[2];
+    if (warm && extrap) {          // Newton-Schulz: F = 1.5 Qpred - 0.5 W Qpred, the orthonormal start basis
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.TH, d.m, 1, d.E, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+    }
     if (warm) {
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            vg_gemm_add(&g, extrap ? d.F : d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.TM, d.m, 1, d.QtPrev, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.TM, d.m, 1, extrap ? d.F : d.QtPrev, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
         }
         VG_HIP(vg_gemm_launch(&g, st));
     }
     VG_MARK(7);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? d.QtPrev : nullptr, d.gwork, d.rotlog, d.roundlog,
+        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? (extrap ? d.F : d.QtPrev) : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
                          (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
         ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
         ej[k].perm = d.perm;
+        ej[k].cp_src = d.QtPrev; ej[k].cp_dst = d.QtPrev2;      // the basis before last, for the next extrapolation
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -433,7 +466,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 
 // ---- HIP-graph cache: the launch sequence of a step is fixed for a plan, so it is captured once per
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
-enum { VG_G_PARTIALS = 0, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_STEP_COLD, VG_G_STEP_WARM, VG_G_COUNT };
+enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
+       VG_G_STEP_WARM_X, VG_G_COUNT };      // _X: warm start from the extrapolated basis
 
 static void graphs_clear(vggp_ctx* c) {
     for (int i = 0; i < VG_G_COUNT; ++i) {
@@ -460,6 +494,13 @@ static int run_graph(vggp_ctx* c, int which, const VgGraphKey& key, hipStream_t 
     }
     VG_HIP(hipGraphLaunch(c->gexec[which], st));
     return VGGP_OK;
+}
+
+// extrapolated warm start: needs the bases of the last two steps (scalar Jacobi variant; VGGP_NO_EXTRAP=1 switches it off)
+static bool vg_extrapolate(const vggp_ctx* c) {
+    static const bool off = getenv("VGGP_NO_EXTRAP") != nullptr;
+    return !off && c->desc.warm_start && !(c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) && c->d[0].have_prev && c->d[1].have_prev &&
+           c->d[0].have_prev2 && c->d[1].have_prev2;
 }
 
 static int set_theta(vggp_ctx* c, const double theta[5]) {
@@ -497,7 +538,14 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     }
     if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
     if (status == VGGP_ENOCONV) { vg_set_error("Jacobi eigensolver did not converge"); return VGGP_ENOCONV; }
-    for (int k = 0; k < 2; ++k) c->d[k].have_prev = true;      // QtPrev holds this step's basis
+    for (int k = 0; k < 2; ++k) {
+        c->d[k].have_prev2 = c->d[k].have_prev;                // QtPrev2 <- previous basis (copied by the replay workgroups)
+        c->d[k].have_prev = true;                              // QtPrev holds this step's basis
+    }
+    if (++c->warm_run >= 512) {                                // periodic cold restart: bounds the drift of orthogonality
+        c->warm_run = 0;
+        for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+    }
     c->have_step = true;
     return VGGP_OK;
 }
@@ -511,7 +559,9 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     if (rc) return rc;
     if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
     const VgGraphKey key{Y, payload, 0.0};
-    rc = run_graph(c, VG_G_PARTIALS, key, st, [&] { return vg_partials_enqueue(c, Y, payload, st); });
+    const bool extrap = vg_extrapolate(c);
+    rc = run_graph(c, extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, key, st,
+                   [&] { return vg_partials_enqueue(c, Y, payload, st, true, extrap); });
     if (rc) return rc;
     c->have_partials = true;
     return VGGP_OK;
@@ -527,8 +577,9 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     if (rc) return rc;
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{nullptr, payload, yy_total};
-    rc = run_graph(c, warm ? VG_G_FINISH_WARM : VG_G_FINISH_COLD, key, st,
-                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true); });
+    const bool extrap = vg_extrapolate(c);       // same state as at the matching vggp_elbo_partials call
+    rc = run_graph(c, warm ? (extrap ? VG_G_FINISH_WARM_X : VG_G_FINISH_WARM) : VG_G_FINISH_COLD, key, st,
+                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap); });
     if (rc) return rc;
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
@@ -544,9 +595,10 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{Y, c->payload, yy_total};
-    rc = run_graph(c, warm ? VG_G_STEP_WARM : VG_G_STEP_COLD, key, st, [&] {
-        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm);
+    const bool extrap = vg_extrapolate(c);
+    rc = run_graph(c, warm ? (extrap ? VG_G_STEP_WARM_X : VG_G_STEP_WARM) : VG_G_STEP_COLD, key, st, [&] {
+        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap);
     });
     if (rc) return rc;
     c->have_partials = true;

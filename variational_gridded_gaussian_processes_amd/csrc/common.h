@@ -26,7 +26,7 @@ void vg_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- batched strided GEMM descriptors (passed by value as kernel argument) -----
-#define VG_GEMM_MAXP 8
+#define VG_GEMM_MAXP 12
 #define VG_BM 64
 #define VG_BN 64
 #define VG_BK 16
@@ -125,6 +125,8 @@ struct VgEigJob {
     int block;            // 1: block-Jacobi variant (m <= 128), 0: scalar cyclic Jacobi
     double tol = 0.0;     // off-diagonal threshold relative to ||G||_F / m (0: VG_EIG_TOL)
     double* Qt2 = nullptr; // optional second copy of Qt (next step's warm-start basis; may alias Qt0)
+    const double* cp_src = nullptr;  // optional: each replay workgroup first copies its column slice cp_src -> cp_dst
+    double* cp_dst = nullptr;        // (keeps the basis before last for the extrapolated warm start; scalar variant only)
     int* perm = nullptr;   // [m] scratch: rank of eigenpair i in decreasing order (scalar variant; null = leave unsorted)
     int fast_switch = 112; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
 };

@@ -7,13 +7,13 @@ struct VgDim {
     double *x = nullptr, *grid = nullptr;
     double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
     double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
-    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr;
+    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr, *QtPrev2 = nullptr;
     double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
     double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
     double2* rotlog = nullptr;
     int *roundlog = nullptr, *counters = nullptr, *status = nullptr, *perm = nullptr;
     int gh_split = 1, max_rounds = 0;
-    bool have_prev = false;
+    bool have_prev = false, have_prev2 = false;     // QtPrev / QtPrev2 hold the bases of the last / the step before
 };
 
 struct VgGraphKey {
@@ -58,8 +58,9 @@ struct vggp_ctx {
     // directions (uploads / all-reduce issued by torch on stream 0 before, q(v) / posterior calls after).
     hipStream_t own_stream = nullptr;
     bool use_graph = true;
-    hipGraphExec_t gexec[5] = {};
-    VgGraphKey gkey[5];
+    hipGraphExec_t gexec[8] = {};
+    VgGraphKey gkey[8];
+    int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
     bool prof = false;
     hipEvent_t ev[VGGP_NSTAGE + 2] = {};
@@ -70,5 +71,5 @@ struct vggp_ctx {
 
 
 int vg_ensure_misc(vggp_ctx* c, size_t bytes);
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true);
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false);
 void vg_masked_free(vggp_ctx* c);

@@ -538,6 +538,12 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
         if (J.Qt0 && i < m && j < m) v = J.Qt0[i * m + j];
         T[i * VG_RP_LD + jj] = v;
     }
+    if (J.cp_src && J.cp_dst) {
+        for (int idx = tid; idx < m * VG_RP_COLS; idx += nthr) {
+            const int i = idx >> csh, j = j0 + (idx & (VG_RP_COLS - 1));
+            if (j < m) J.cp_dst[i * m + j] = J.cp_src[i * m + j];
+        }
+    }
     const int jj = wave * 4 + (lane & 3);                   // this lane's column inside the block
     const bool colwave = wave * 4 < VG_RP_COLS;              // waves beyond the tile only help with the loads
     int consumed = 0;
