@@ -118,46 +118,91 @@ static int pick_split(int tiles, int K, int target) {
 }
 
 static void layout(vggp_ctx* c, Bump& b) {
+    // Allocation ORDER matters: the small kernels of a step are latency chains whose first loads miss everything
+    // (the producer ran on another XCD), and each distinct 2 MB region they touch adds an address-translation miss on
+    // top.  So the arrays are grouped by the stage that reads them -- tail (m-space) arrays together, eigen-stage arrays
+    // together, factor-stage arrays together -- and the large streaming buffers (operands over the grid, split-K slabs,
+    // rotation log) come last.
     const vggp_desc& D = c->desc;
     const long n1 = D.n1, n2 = D.n2, m1 = D.m1, m2 = D.m2;
+    // ---- tail: m-space stage and final reduction
+    c->out = b.take<double>(8);
+    c->theta = b.take<double>(8);
+    c->rowpart = b.take<double>(m1 * 8);
+    c->r1 = b.take<double>(m1);
+    c->r1l = b.take<double>(m1);
+    c->r2 = b.take<double>(m2);
+    c->r2l = b.take<double>(m2);
+    c->dotpart = b.take<double>(64 * 4);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        const long m = d.m, n = d.n, m2e = m + (m & 1);
-        const int glen = d.basis == VGGP_BASIS_B0 ? m + 1 : m;
-        d.x = b.take<double>(n);
-        d.grid = b.take<double>(glen);
-        d.K0 = b.take<double>(m * m);
-        d.dK0 = b.take<double>(m * m);
-        d.AD = b.take<double>(2 * m * n);
-        d.L0 = b.take<double>(m * m);
-        d.Linv0 = b.take<double>(m * m);
-        d.BV = b.take<double>(2 * m * n);
-        d.X = b.take<double>(m * m);
-        d.Mk = b.take<double>(m * m);
-        d.GH = b.take<double>(2 * m * m);
-        static const char* ghe = getenv("VGGP_GH_TARGET");
-        d.gh_split = pick_split((int)(((m + 63) / 64) * ((m + 63) / 64)), (int)n, ghe ? atoi(ghe) : 32);
-        d.GHslab = b.take<double>((size_t)d.gh_split * 2 * m * m);
-        d.Gw = b.take<double>(m * m);
+        const long m = d.m, m2e = m + (m & 1);
         d.lam0 = b.take<double>(m);
-        d.Qt = b.take<double>(m * m);
-        d.QtPrev = b.take<double>(m * m);
-        d.QtPrev2 = b.take<double>(m * m);
-        d.TM = b.take<double>(m * m);
-        d.TH = b.take<double>(m * m);
-        d.E = b.take<double>(m * m);
-        d.F = b.take<double>(m * m);
-        d.RQ = b.take<double>(m * m);
-        d.RQsq = b.take<double>(m * m);
-        d.chol_scratch = b.take<double>(m * (m + 1));
-        d.gwork = b.take<double>(m2e * (m2e + 1));
         d.jitter = b.take<double>(2);
-        d.max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
-        d.rotlog = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
-        d.roundlog = b.take<int>(d.max_rounds);
         d.counters = b.take<int>(4);
         d.perm = b.take<int>(m2e);
         d.status = b.take<int>(2);
+    }
+    c->invD = b.take<double>(m1 * m2);
+    c->beta = b.take<double>(m1 * m2);
+    c->bl2 = b.take<double>(m1 * m2);
+    c->bl1 = b.take<double>(m1 * m2);
+    c->X1 = b.take<double>(m1 * m1);
+    c->X1l = b.take<double>(m1 * m1);
+    c->X2 = b.take<double>(m2 * m2);
+    c->X2l = b.take<double>(m2 * m2);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        d.E = b.take<double>((long)d.m * d.m);
+        d.F = b.take<double>((long)d.m * d.m);
+    }
+    c->P3 = b.take<double>(3 * m1 * m2);
+    c->T3 = b.take<double>(3 * m1 * m2);
+    // ---- eigen stage
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const long m = d.m;
+        d.TM = b.take<double>(m * m);
+        d.TH = b.take<double>(m * m);
+        d.Qt = b.take<double>(m * m);
+        d.QtPrev = b.take<double>(m * m);
+        d.QtPrev2 = b.take<double>(m * m);
+        d.Gw = b.take<double>(m * m);
+        d.GH = b.take<double>(2 * m * m);
+        d.Mk = b.take<double>(m * m);
+    }
+    c->payload_len = 2 * m2 * m2 + 3 * m1 * m2;
+    c->payload = b.take<double>(c->payload_len);
+    // ---- factor stage
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const long m = d.m;
+        const int glen = d.basis == VGGP_BASIS_B0 ? m + 1 : m;
+        d.grid = b.take<double>(glen);
+        d.K0 = b.take<double>(m * m);
+        d.dK0 = b.take<double>(m * m);
+        d.L0 = b.take<double>(m * m);
+        d.Linv0 = b.take<double>(m * m);
+        d.X = b.take<double>(m * m);
+        d.chol_scratch = b.take<double>(m * (m + 1));
+        d.RQ = b.take<double>(m * m);
+        d.RQsq = b.take<double>(m * m);
+    }
+    c->wq = b.take<double>(2 * m1 * m2);
+    // ---- large streaming buffers
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const long m = d.m, n = d.n, m2e = m + (m & 1);
+        d.x = b.take<double>(n);
+        d.AD = b.take<double>(2 * m * n);
+        d.BV = b.take<double>(2 * m * n);
+        static const char* ghe = getenv("VGGP_GH_TARGET");
+        d.gh_split = pick_split((int)(((m + 63) / 64) * ((m + 63) / 64)), (int)n, ghe ? atoi(ghe) : 32);
+        d.GHslab = b.take<double>((size_t)d.gh_split * 2 * m * m);
+        d.gwork = b.take<double>(m2e * (m2e + 1));
+        d.max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
+        d.rotlog = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
+        d.roundlog = b.take<int>(d.max_rounds);
     }
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
     static const char* ste = getenv("VGGP_ST_TARGET");
@@ -166,27 +211,6 @@ static void layout(vggp_ctx* c, Bump& b) {
     const int cc_tiles = (int)(((2 * m1 + 63) / 64) * ((m2 + 63) / 64));
     c->cc_split = pick_split(cc_tiles, (int)n1, 64);
     c->CCslab = b.take<double>((size_t)c->cc_split * 3 * m1 * m2);
-    c->payload_len = 2 * m2 * m2 + 3 * m1 * m2;
-    c->payload = b.take<double>(c->payload_len);
-    c->T3 = b.take<double>(3 * m1 * m2);
-    c->P3 = b.take<double>(3 * m1 * m2);
-    c->beta = b.take<double>(m1 * m2);
-    c->bl2 = b.take<double>(m1 * m2);
-    c->bl1 = b.take<double>(m1 * m2);
-    c->invD = b.take<double>(m1 * m2);
-    c->rowpart = b.take<double>(m1 * 8);
-    c->r1 = b.take<double>(m1);
-    c->r1l = b.take<double>(m1);
-    c->r2 = b.take<double>(m2);
-    c->r2l = b.take<double>(m2);
-    c->dotpart = b.take<double>(64 * 4);
-    c->X1 = b.take<double>(m1 * m1);
-    c->X1l = b.take<double>(m1 * m1);
-    c->X2 = b.take<double>(m2 * m2);
-    c->X2l = b.take<double>(m2 * m2);
-    c->wq = b.take<double>(2 * m1 * m2);
-    c->out = b.take<double>(8);
-    c->theta = b.take<double>(8);
 }
 
 static int check_dim(int kind, int basis, long n, long m, const char* which) {
@@ -851,6 +875,12 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, con
 }
 
 // diagnostic builds only (-DVG_EIG_STAMP): copy the head of the scratch buffer to the host
+extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
+    if (!c || !c->out) return VGGP_EINVAL;
+    VG_HIP(hipMemcpy(host8, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return VGGP_OK;
+}
+
 extern "C" int vggp_debug_read_misc(vggp_ctx* c, void* host, int64_t bytes) {
     if (!c || !c->misc || (size_t)bytes > c->misc_bytes) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host, c->misc, bytes, hipMemcpyDeviceToHost));

@@ -27,9 +27,40 @@ __device__ __forceinline__ double vg_block_sum(double v, double* red) {
     return t;
 }
 
+// agent-scope (all XCDs) write-through store / cache-bypassing load: the per-XCD L2s are not coherent with each other
+// for ordinary accesses, and a full __threadfence() costs a whole-L2 write-back per call
+__device__ __forceinline__ void vg_st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double vg_ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NV>
+__device__ __forceinline__ void vg_block_sum_n(double (&v)[NV], double* red /* >= 4 * NV */) {
+    // butterfly with the NV shuffles of a step issued together: one cross-lane latency per step instead of one per value
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double t[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) t[q] = __shfl_xor(v[q], off);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] += t[q];
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[(threadIdx.x >> 6) * NV + q] = v[q];
+    }
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += red[w * NV + q];
+        v[q] = t;
+    }
+}
+
 // ---- D-stage: one workgroup per row i1 ---------------------------------------------
 __global__ __launch_bounds__(256) void vg_dstage_kernel(const VgMspace ms) {
-    __shared__ double red[16];
+    __shared__ double red[4 * 10];
     const int i1 = blockIdx.x, m2 = ms.m2;
     const long msz = (long)ms.m1 * m2;
     const double s1 = ms.theta[2], s2 = ms.theta[3], v = ms.theta[4];
@@ -59,8 +90,7 @@ __global__ __launch_bounds__(256) void vg_dstage_kernel(const VgMspace ms) {
         acc[8] += iD;
         acc[9] += l2 * iD;
     }
-#pragma unroll
-    for (int q = 0; q < 10; ++q) acc[q] = vg_block_sum(acc[q], red);
+    vg_block_sum_n<10>(acc, red);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) ms.rowpart[i1 * 8 + q] = acc[q];
@@ -83,118 +113,167 @@ hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st) {
 #define VG_NFIN 23          // scalars the final combination needs
 
 // sums NV values per thread over the workgroup in one pass (wave shuffles, then one LDS stage); result in every thread
-template <int NV>
-__device__ __forceinline__ void vg_block_sum_n(double (&v)[NV], double* red /* >= 4 * NV */) {
+// Inputs of the final combination that do not depend on this launch's partial sums: loaded by EVERY workgroup at kernel
+// start, together with its own operands (one memory round trip, ~2-4 us when the producer ran on another XCD), so that
+// the workgroup that turns out to be last only waits for the partials.
+struct VgFinPre { double S[VG_NFIN]; double e2, ff2; };
+__device__ __forceinline__ void vg_final_prefetch(const VgMspace& ms, VgFinPre& P) {
+    const int m1 = ms.m1, m2 = ms.m2, i = threadIdx.x;
+    const double s1 = ms.theta[2], s2 = ms.theta[3];
+    const bool o1 = i < m1, o2 = i < m2;
+    double rp[7];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = vg_wave_sum(v[q]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
+    for (int q = 0; q < 7; ++q) rp[q] = o1 ? ms.rowpart[i * 8 + q] : 0.0;
+    const double la1 = o1 ? ms.lam1[i] : 0.0, e1 = o1 ? ms.E1[(long)i * m1 + i] : 0.0, f1 = o1 ? ms.F1[(long)i * m1 + i] : 0.0;
+    const double r1 = o1 ? ms.r1[i] : 0.0, r1l = o1 ? ms.r1l[i] : 0.0;
+    const double la2 = o2 ? ms.lam2[i] : 0.0, e2 = o2 ? ms.E2[(long)i * m2 + i] : 0.0, f2 = o2 ? ms.F2[(long)i * m2 + i] : 0.0;
 #pragma unroll
-        for (int q = 0; q < NV; ++q) red[(threadIdx.x >> 6) * NV + q] = v[q];
-    }
-    __syncthreads();
-    const int nw = (blockDim.x + 63) >> 6;
+    for (int q = 0; q < VG_NFIN; ++q) P.S[q] = 0.0;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        double t = 0.0;
-        for (int w = 0; w < nw; ++w) t += red[w * NV + q];
-        v[q] = t;
-    }
+    for (int q = 0; q < 7; ++q) P.S[q] = rp[q];
+    P.S[11] = la1; P.S[12] = la2;
+    const double ff1 = 2.0 * s1 * f1, ff2 = 2.0 * s2 * f2;
+    P.S[13] = e1; P.S[14] = e1 * r1; P.S[15] = ff1 * r1l; P.S[16] = ff1; P.S[17] = e1 * s1 * la1;
+    P.S[18] = e2; P.S[21] = ff2; P.S[22] = e2 * s2 * la2;
+    P.e2 = e2; P.ff2 = ff2;
 }
 
-__device__ void vg_final_body(const VgMspace& ms, double* red) {
+// S[0..6]: row partials; [7..10]: dot products; [11],[12]: sum lam; [13..17]: dimension 1 sums; [18..22]: dimension 2
+__device__ void vg_final_body(const VgMspace& ms, VgFinPre& P, double* red, double* stage /* 16 doubles, not aliased with red */) {
     const int m1 = ms.m1, m2 = ms.m2;
     const double s1 = ms.theta[2], s2 = ms.theta[3], v = ms.theta[4];
     const double N = ms.n_total, yy = ms.yy;
-    // S[0..6]: row partials; [7..10]: dot products; [11],[12]: sum lam; [13..17]: dimension 1 sums; [18..22]: dimension 2
-    double S[VG_NFIN];
+    double (&S)[VG_NFIN] = P.S;
+    {   // the partial sums of all workgroups (write-through stores there, cache-bypassing loads here)
+        const int i = threadIdx.x;
+        const bool o2 = i < m2, op = i < VG_NPART;
+        const double r2 = o2 ? vg_ld_agent(ms.r2 + i) : 0.0, r2l = o2 ? vg_ld_agent(ms.r2l + i) : 0.0;
+        double dpv[4];
 #pragma unroll
-    for (int q = 0; q < VG_NFIN; ++q) S[q] = 0.0;
-    for (int i = threadIdx.x; i < m1; i += blockDim.x) {
+        for (int q = 0; q < 4; ++q) dpv[q] = op ? vg_ld_agent(ms.dotpart + i * 4 + q) : 0.0;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) S[q] += ms.rowpart[i * 8 + q];
-        S[11] += ms.lam1[i];
-        const double e = ms.E1[(long)i * m1 + i], f = 2.0 * s1 * ms.F1[(long)i * m1 + i];
-        S[13] += e; S[14] += e * ms.r1[i]; S[15] += f * ms.r1l[i]; S[16] += f; S[17] += e * s1 * ms.lam1[i];
-    }
-    for (int i = threadIdx.x; i < m2; i += blockDim.x) {
-        S[12] += ms.lam2[i];
-        const double e = ms.E2[(long)i * m2 + i], f = 2.0 * s2 * ms.F2[(long)i * m2 + i];
-        S[18] += e; S[19] += e * ms.r2[i]; S[20] += f * ms.r2l[i]; S[21] += f; S[22] += e * s2 * ms.lam2[i];
-    }
-    for (int i = threadIdx.x; i < VG_NPART; i += blockDim.x) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) S[7 + q] += ms.dotpart[i * 4 + q];
+        for (int q = 0; q < 4; ++q) S[7 + q] = dpv[q];
+        S[19] = P.e2 * r2; S[20] = P.ff2 * r2l;
     }
     vg_block_sum_n<VG_NFIN>(S, red);
     if (threadIdx.x == 0) {
+        // one thread, dependent f64 chain: reciprocals once, multiplications after (a software f64 division is ~30
+        // dependent instructions; the original 17 of them cost ~6 us here)
+        const double iv = 1.0 / v, is1 = 1.0 / s1, is2 = 1.0 / s2;
+        const double iv2 = iv * iv, hiv = 0.5 * iv;
         const double sl1 = s1 * S[11], sl2 = s2 * S[12];
         const double EX1 = S[7], FX1 = 2.0 * s1 * S[8], EX2 = S[9], FX2 = 2.0 * s2 * S[10];
-        const double v2 = v * v;
-        const double elbo = -0.5 * (N * 1.8378770664093453 + N * log(v) + S[0] + yy / v - S[1] / v2)
-                            - (N * s1 * s2 - sl1 * sl2) / (2.0 * v);
-        const double quad1 = 2.0 * S[5] - EX1 - FX1 / v;
-        const double quad2 = 2.0 * S[6] - EX2 - FX2 / v;
-        const double g_l1 = -0.5 * (S[14] + S[15] / v - (double)m2 * S[13] - quad1 / v2) + sl2 / (2.0 * v) * (S[16] - S[17]);
-        const double g_l2 = -0.5 * (S[19] + S[20] / v - (double)m1 * S[18] - quad2 / v2) + sl1 / (2.0 * v) * (S[21] - S[22]);
-        const double common = -0.5 * (S[3] - S[2] / v2);
-        const double g_s1 = common / s1 + sl1 * sl2 / (2.0 * v * s1) - N * s2 / (2.0 * v);
-        const double g_s2 = common / s2 + sl1 * sl2 / (2.0 * v * s2) - N * s1 / (2.0 * v);
-        const double g_v = -0.5 * (N / v - S[3] / v - yy / v2 + S[4] / (v2 * v)) + (N * s1 * s2 - sl1 * sl2) / (2.0 * v2);
+        const double Nss = N * s1 * s2, sll = sl1 * sl2;
+        const double elbo = -0.5 * (N * 1.8378770664093453 + N * log(v) + S[0] + yy * iv - S[1] * iv2) - (Nss - sll) * hiv;
+        const double quad1 = 2.0 * S[5] - EX1 - FX1 * iv;
+        const double quad2 = 2.0 * S[6] - EX2 - FX2 * iv;
+        const double g_l1 = -0.5 * (S[14] + S[15] * iv - (double)m2 * S[13] - quad1 * iv2) + sl2 * hiv * (S[16] - S[17]);
+        const double g_l2 = -0.5 * (S[19] + S[20] * iv - (double)m1 * S[18] - quad2 * iv2) + sl1 * hiv * (S[21] - S[22]);
+        const double common = -0.5 * (S[3] - S[2] * iv2);
+        const double g_s1 = common * is1 + sll * hiv * is1 - N * s2 * hiv;
+        const double g_s2 = common * is2 + sll * hiv * is2 - N * s1 * hiv;
+        const double g_v = -0.5 * (N * iv - S[3] * iv - yy * iv2 + S[4] * iv2 * iv) + (Nss - sll) * 0.5 * iv2;
         const double o[6] = {elbo, g_l1, g_l2, g_s1, g_s2, g_v};
 #pragma unroll
-        for (int q = 0; q < 6; ++q) ms.out[q] = o[q];
-        if (ms.hout) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) ms.hout->out[q] = o[q];
-            for (int k = 0; k < 2; ++k) {
-                ms.hout->jitter[k] = ms.jit[k] ? *ms.jit[k] : 0.0;
-                ms.hout->status[k] = ms.status[k] ? *ms.status[k] : 0;
-                for (int q = 0; q < 4; ++q) ms.hout->counters[k][q] = ms.counters[k] ? ms.counters[k][q] : 0;
-            }
+        for (int q = 0; q < 6; ++q) { ms.out[q] = o[q]; stage[q] = o[q]; }
+        stage[6] = stage[7] = 0.0;
+    }
+    // results + diagnostics go to the pinned host block as ONE 128-byte burst: the block is staged in LDS (layout of
+    // VgHostOut: out[8], jitter[2], counters[2][4], status[2]) and 16 lanes store one 8-byte word each
+    if (ms.hout) {
+        int* ired = reinterpret_cast<int*>(stage + 10);
+        if (threadIdx.x < 2) stage[8 + threadIdx.x] = ms.jit[threadIdx.x] ? *ms.jit[threadIdx.x] : 0.0;
+        if (threadIdx.x >= 32 && threadIdx.x < 40) {
+            const int k = (threadIdx.x - 32) >> 2, q = (threadIdx.x - 32) & 3;
+            ired[k * 4 + q] = ms.counters[k] ? ms.counters[k][q] : 0;
         }
+        if (threadIdx.x >= 64 && threadIdx.x < 66) ired[8 + threadIdx.x - 64] = ms.status[threadIdx.x - 64] ? *ms.status[threadIdx.x - 64] : 0;
+        __syncthreads();
+        static_assert(sizeof(VgHostOut) == 15 * 8, "VgHostOut layout");
+        if (threadIdx.x < 15) reinterpret_cast<double*>(ms.hout)[threadIdx.x] = stage[threadIdx.x];
     }
 }
 
+#ifdef VG_FIN_STAMP
+#define FS(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FS(var)
+#endif
 __global__ __launch_bounds__(256) void vg_partial_kernel(const VgMspace ms) {
+    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+    FS(f0);
     __shared__ double red[4 * VG_NFIN];
+    __shared__ double stage[16];
     __shared__ int s_last;
     const int m1 = ms.m1, m2 = ms.m2, b = blockIdx.x;
     const double s1 = ms.theta[2];
-    // column sums: block b owns columns b, b + VG_NPART, ...
-    for (int i2 = b; i2 < m2; i2 += VG_NPART) {
-        double ac[2] = {0.0, 0.0};
-        for (int i1 = threadIdx.x; i1 < m1; i1 += blockDim.x) {
-            const double iD = ms.invD[(long)i1 * m2 + i2];
-            ac[0] += iD;
-            ac[1] += s1 * ms.lam1[i1] * iD;
+    VgFinPre P;
+    vg_final_prefetch(ms, P);
+    // Every operand of this workgroup comes straight from the previous kernels (cold in this XCD's L2, ~2 us per
+    // dependent round trip), so all loads are issued before the first reduction: up to VG_PCOLS columns of 1/D per
+    // workgroup (column sums) and its slices of the four m x m dot products.
+    constexpr int VG_PCOLS = 4;                                   // columns b, b + 64, ... (m2 <= 256)
+    double v8[2 * VG_PCOLS + 4];
+#pragma unroll
+    for (int q = 0; q < 2 * VG_PCOLS + 4; ++q) v8[q] = 0.0;
+    // straight-line predicated loads (m <= 256 = blockDim.x, so one element per thread and column): a loop with a
+    // run-time trip count would make the compiler wait for each loop's loads before issuing the next loop's
+    {
+        const int i1 = threadIdx.x;
+        const bool rok = i1 < m1;
+        double iD[VG_PCOLS];
+        const double l1 = rok ? s1 * ms.lam1[i1] : 0.0;
+#pragma unroll
+        for (int cidx = 0; cidx < VG_PCOLS; ++cidx) {
+            const int i2 = b + cidx * VG_NPART;
+            iD[cidx] = (rok && i2 < m2) ? ms.invD[(long)i1 * m2 + i2] : 0.0;
         }
-        vg_block_sum_n<2>(ac, red);
-        if (threadIdx.x == 0) { ms.r2[i2] = ac[0]; ms.r2l[i2] = ac[1]; }
+        double e1[4], x1[4], f1v[4], xl1[4], e2[4], x2[4], f2v[4], xl2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                             // m^2 / (64 * 256) <= 4 slices per thread
+            const long idx = (long)b * blockDim.x + threadIdx.x + (long)u * VG_NPART * blockDim.x;
+            const bool o1 = idx < (long)m1 * m1, o2 = idx < (long)m2 * m2;
+            e1[u] = o1 ? ms.E1[idx] : 0.0; x1[u] = o1 ? ms.X1[idx] : 0.0;
+            f1v[u] = o1 ? ms.F1[idx] : 0.0; xl1[u] = o1 ? ms.X1l[idx] : 0.0;
+            e2[u] = o2 ? ms.E2[idx] : 0.0; x2[u] = o2 ? ms.X2[idx] : 0.0;
+            f2v[u] = o2 ? ms.F2[idx] : 0.0; xl2[u] = o2 ? ms.X2l[idx] : 0.0;
+        }
+#pragma unroll
+        for (int cidx = 0; cidx < VG_PCOLS; ++cidx) { v8[2 * cidx] = iD[cidx]; v8[2 * cidx + 1] = l1 * iD[cidx]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v8[2 * VG_PCOLS + 0] += e1[u] * x1[u];
+            v8[2 * VG_PCOLS + 1] += f1v[u] * xl1[u];
+            v8[2 * VG_PCOLS + 2] += e2[u] * x2[u];
+            v8[2 * VG_PCOLS + 3] += f2v[u] * xl2[u];
+        }
     }
-    // dot-product slices
-    double dp[4] = {0.0, 0.0, 0.0, 0.0};
-    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m1 * m1; idx += (long)VG_NPART * blockDim.x) {
-        dp[0] += ms.E1[idx] * ms.X1[idx];
-        dp[1] += ms.F1[idx] * ms.X1l[idx];
-    }
-    for (long idx = (long)b * blockDim.x + threadIdx.x; idx < (long)m2 * m2; idx += (long)VG_NPART * blockDim.x) {
-        dp[2] += ms.E2[idx] * ms.X2[idx];
-        dp[3] += ms.F2[idx] * ms.X2l[idx];
-    }
-    vg_block_sum_n<4>(dp, red);
+    FS(f1);
+    vg_block_sum_n<2 * VG_PCOLS + 4>(v8, red);
+    FS(f2);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ms.dotpart[b * 4 + q] = dp[q];
-        __threadfence();                                         // release this workgroup's partial sums ...
-        const int t = atomicAdd(ms.ticket, 1);                   // ... before drawing the ticket
+        for (int cidx = 0; cidx < VG_PCOLS; ++cidx) {
+            const int i2 = b + cidx * VG_NPART;
+            if (i2 < m2) { vg_st_agent(ms.r2 + i2, v8[2 * cidx]); vg_st_agent(ms.r2l + i2, v8[2 * cidx + 1]); }
+        }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vg_st_agent(ms.dotpart + b * 4 + q, v8[2 * VG_PCOLS + q]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this workgroup's partial sums are at the memory side ...
+        const int t = __hip_atomic_fetch_add(ms.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the ticket
         s_last = (t == VG_NPART - 1);
     }
     __syncthreads();
+    FS(f3);
     if (!s_last) return;
-    __threadfence();                                             // acquire: every other workgroup's partial sums
-    if (threadIdx.x == 0) *ms.ticket = 0;                        // self-cleaning for the next launch
-    vg_final_body(ms, red);
+    if (threadIdx.x == 0) __hip_atomic_store(ms.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+    vg_final_body(ms, P, red, stage);
+#ifdef VG_FIN_STAMP
+    FS(f4);
+    if (threadIdx.x == 0) { ms.out[6] = (double)(f1 - f0) + 1e-6 * (double)(f2 - f1); ms.out[7] = (double)(f3 - f2) + 1e-6 * (double)(f4 - f3); }
+#endif
 }
 
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st) {
