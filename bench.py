@@ -212,8 +212,10 @@ def main():
         roofline = {
             "kernel": "vg_gemm_kernel (launch group '%s': the only pass over Y)" % proj,
             "bound": "mfma", "achieved": proj_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": proj_tflops / FP64_PEAK_TFLOPS, "traffic": None,
+            "frac": proj_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(),
             "flops_per_launch": flops[proj], "avg_launch_us": stages_us[proj],
+            # algorithmic bytes of that launch: Y once, [B;V] of both dimensions once, un-split outputs [G;H] x2 and S
+            "algorithmic_bytes_per_launch": 8 * (n1 * n2_loc + 2 * (m * n1 + m * n2_loc) + 4 * m * m + 2 * m * n1),
             "dominant_stage_by_time": dom, "dominant_stage_us": stages_us[dom],
             "step_dense_flops": step_flops,
             "step_frac_of_fp64_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -243,6 +245,17 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    runs of this same command, profiles/r1_pmc_traffic.json written by tools/pmc_traffic.py); None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def kron_solve_bench(eng, n, reps=20):

@@ -61,7 +61,8 @@ def test_factor_build_b0(engine):
 
 
 @pytest.mark.parametrize("m,kind,ell", [(7, "matern12", 0.3), (64, "matern32", 0.2), (128, "matern52", 0.2),
-                                        (128, "rbf", 0.2), (150, "matern32", 0.1)])
+                                        (128, "rbf", 0.2), (150, "matern32", 0.1), (300, "rbf", 0.05),
+                                        (1024, "matern32", 0.05)])
 def test_cholesky_inverse(engine, m, kind, ell):
     z = np.linspace(0, 1, m)
     K, _ = Kr.points_factor(kind, z, z, ell)
@@ -70,7 +71,8 @@ def test_cholesky_inverse(engine, m, kind, ell):
     assert jit == jr
     L, Li = L.cpu().numpy(), Li.cpu().numpy()
     Kj = K + jit * np.eye(m)
-    assert rel(L @ L.T, Kj) < 1e-13
+    # m > 128: blocked path, panels solved with the explicit inverse of the (ill-conditioned) diagonal blocks
+    assert rel(L @ L.T, Kj) < (1e-13 if m <= 128 else 2e-12)
     assert np.abs(np.triu(L, 1)).max() == 0 and np.abs(np.triu(Li, 1)).max() == 0
     # L Li = I to conditioning
     assert np.abs(L @ Li - np.eye(m)).max() < 1e-9 * max(1.0, np.linalg.cond(Lr) * 1e-4)

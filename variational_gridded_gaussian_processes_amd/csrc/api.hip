@@ -771,12 +771,50 @@ extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double*
     return VGGP_OK;
 }
 
+// adds jit to the diagonal of the m x m copy W of K (one launch per jitter attempt of the blocked path)
+__global__ void vg_copy_jitter_kernel(const double* K, double* W, long m, double jit) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * m) return;
+    W[idx] = K[idx] + ((idx / m == idx % m) ? jit : 0.0);
+}
+
 extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, double* L, double* Linv, double* jitter_out,
                                      void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
-    VG_REQUIRE(K && L && Linv && m >= 1 && m <= 1024, "vggp_cholesky_inverse: bad argument (1 <= m <= 1024)");
+    VG_REQUIRE(K && L && Linv && m >= 1 && m <= 8192, "vggp_cholesky_inverse: bad argument (1 <= m <= 8192)");
     VG_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    if (m > 128) {
+        // beyond one workgroup: blocked factorisation (128-wide panels by the single-workgroup kernel, the rest by MFMA
+        // GEMMs); the jitter schedule is walked on the host, one attempt per level
+        const size_t nblk = (size_t)(m + VG_DENSE_MB - 1) / VG_DENSE_MB;
+        const size_t need = ((size_t)m * m + nblk * VG_DENSE_MB * VG_DENSE_MB + (size_t)VG_DENSE_MB * m + VG_DENSE_MB * (VG_DENSE_MB + 1) + 64) * sizeof(double);
+        int rc = vg_ensure_misc(c, need);
+        if (rc) return rc;
+        double* p = (double*)c->misc;
+        VgDenseChol w{};
+        w.S = p; p += (size_t)m * m;
+        w.DI = p; p += nblk * VG_DENSE_MB * VG_DENSE_MB;
+        w.Tmp = p; p += (size_t)VG_DENSE_MB * m;
+        w.scratch = p; p += VG_DENSE_MB * (VG_DENSE_MB + 1);
+        w.jit = p; p += 8;
+        w.status = reinterpret_cast<int*>(p);
+        w.L = L; w.X = Linv; w.M = m; w.Sinv = nullptr;
+        static const double levels[4] = {0.0, 1e-8, 1e-7, 1e-6};
+        for (int lvl = 0; lvl < 4; ++lvl) {
+            VG_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int), st));
+            hipLaunchKernelGGL(vg_copy_jitter_kernel, dim3((unsigned)(((size_t)m * m + 255) / 256)), dim3(256), 0, st, K, w.S, (long)m, levels[lvl]);
+            VG_HIP(hipGetLastError());
+            if ((rc = vg_blocked_chol_inverse(w, st))) return rc;
+            int hs = 0;
+            VG_HIP(hipMemcpyAsync(&hs, w.status, sizeof(int), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+            if (!hs) { if (jitter_out) *jitter_out = levels[lvl]; return VGGP_OK; }
+        }
+        if (jitter_out) *jitter_out = -1.0;
+        vg_set_error("vggp_cholesky_inverse: not positive definite after jitter 1e-6");
+        return VGGP_ENOTPD;
+    }
     int rc = vg_ensure_misc(c, (size_t)(m * (m + 1) + 16) * sizeof(double));
     if (rc) return rc;
     double* scratch = (double*)c->misc;

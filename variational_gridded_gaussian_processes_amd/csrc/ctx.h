@@ -71,5 +71,9 @@ struct vggp_ctx {
 
 
 int vg_ensure_misc(vggp_ctx* c, size_t bytes);
+// blocked dense Cholesky + inverse for matrices beyond one workgroup (masked.hip); S is destroyed; status != 0 on failure
+#define VG_DENSE_MB 128
+struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };
+int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st);
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false);
 void vg_masked_free(vggp_ctx* c);

@@ -244,40 +244,49 @@ static int gemm1(const double* A, long sa_m, long sa_k, const double* B, long sb
     return VGGP_OK;
 }
 
-// Sg (M x M, SPD, destroyed) -> Lg (lower), Xg = Lg^{-1}, Sinv = Sg^{-1}
-static int dense_chol_inverse(vggp_ctx* c, VgMasked& w, hipStream_t st) {
+// S (M x M, SPD, destroyed) -> L (lower), X = L^{-1}, optionally Sinv = S^{-1}.  Blocked right-looking Cholesky with
+// VG_MB-wide panels: diagonal blocks by the single-workgroup kernel (chol.hip), panels and trailing updates by the MFMA
+// GEMM; then the blocked inverse of the factor.  Shared with vggp_cholesky_inverse for m > 128 (ctx.h).
+int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st) {
     const int M = (int)w.M;
+    const int nblk = (M + VG_MB - 1) / VG_MB;
     int rc;
-    VG_HIP(hipMemsetAsync(w.Lg, 0, sizeof(double) * w.M * w.M, st));
-    VG_HIP(hipMemsetAsync(w.Xg, 0, sizeof(double) * w.M * w.M, st));
-    for (int kb = 0; kb < w.nblk; ++kb) {
+    VG_HIP(hipMemsetAsync(w.L, 0, sizeof(double) * w.M * w.M, st));
+    VG_HIP(hipMemsetAsync(w.X, 0, sizeof(double) * w.M * w.M, st));
+    for (int kb = 0; kb < nblk; ++kb) {
         const int k0 = kb * VG_MB, nbk = std::min(VG_MB, M - k0), rest = M - k0 - nbk;
         VgClearArgs clr;
-        clr.n = 1; clr.ptr[0] = reinterpret_cast<int*>(w.cholscratch); clr.nwords[0] = 16;
+        clr.n = 1; clr.ptr[0] = reinterpret_cast<int*>(w.scratch); clr.nwords[0] = 16;
         VG_HIP(vg_clear_launch(&clr, st));
-        VgCholJob j{w.Sg + (long)k0 * M + k0, w.Lg + (long)k0 * M + k0, w.DI + (long)kb * VG_MB * VG_MB, w.cholscratch, w.choljit,
-                    w.cholstatus, nbk};
+        VgCholJob j{w.S + (long)k0 * M + k0, w.L + (long)k0 * M + k0, w.DI + (long)kb * VG_MB * VG_MB, w.scratch, w.jit,
+                    w.status, nbk};
         j.ldk = M; j.ldl = M; j.only_level0 = 1;
         VG_HIP(vg_chol_launch(&j, 1, st));
         if (rest > 0) {
             // panel: L[i, kb] = A[i, kb] Linv_kk^T ;  trailing: A[i, j] -= L[i, kb] L[j, kb]^T
             const double* DIk = w.DI + (long)kb * VG_MB * VG_MB;
-            if ((rc = gemm1(w.Sg + (long)(k0 + nbk) * M + k0, M, 1, DIk, 1, nbk, w.Lg + (long)(k0 + nbk) * M + k0, M, rest, nbk, nbk, st))) return rc;
-            const double* Lp = w.Lg + (long)(k0 + nbk) * M + k0;
-            if ((rc = gemm1(Lp, M, 1, Lp, 1, M, w.Sg + (long)(k0 + nbk) * M + (k0 + nbk), M, rest, rest, nbk, st, -1.0, 1))) return rc;
+            if ((rc = gemm1(w.S + (long)(k0 + nbk) * M + k0, M, 1, DIk, 1, nbk, w.L + (long)(k0 + nbk) * M + k0, M, rest, nbk, nbk, st))) return rc;
+            const double* Lp = w.L + (long)(k0 + nbk) * M + k0;
+            if ((rc = gemm1(Lp, M, 1, Lp, 1, M, w.S + (long)(k0 + nbk) * M + (k0 + nbk), M, rest, rest, nbk, st, -1.0, 1))) return rc;
         }
     }
     // blocked inverse of the lower factor: X[k,k] = inv(L_kk); X[i, :i] = -inv(L_ii) (L[i, :i] X[:i, :i])
-    for (int kb = 0; kb < w.nblk; ++kb) {
+    for (int kb = 0; kb < nblk; ++kb) {
         const int k0 = kb * VG_MB, nbk = std::min(VG_MB, M - k0);
-        VG_HIP(hipMemcpy2DAsync(w.Xg + (long)k0 * M + k0, sizeof(double) * M, w.DI + (long)kb * VG_MB * VG_MB, sizeof(double) * nbk,
+        VG_HIP(hipMemcpy2DAsync(w.X + (long)k0 * M + k0, sizeof(double) * M, w.DI + (long)kb * VG_MB * VG_MB, sizeof(double) * nbk,
                                 sizeof(double) * nbk, nbk, hipMemcpyDeviceToDevice, st));
         if (kb == 0) continue;
-        if ((rc = gemm1(w.Lg + (long)k0 * M, M, 1, w.Xg, M, 1, w.Tmp, k0, nbk, k0, k0, st))) return rc;
-        if ((rc = gemm1(w.DI + (long)kb * VG_MB * VG_MB, nbk, 1, w.Tmp, k0, 1, w.Xg + (long)k0 * M, M, nbk, k0, nbk, st, -1.0, 0))) return rc;
+        if ((rc = gemm1(w.L + (long)k0 * M, M, 1, w.X, M, 1, w.Tmp, k0, nbk, k0, k0, st))) return rc;
+        if ((rc = gemm1(w.DI + (long)kb * VG_MB * VG_MB, nbk, 1, w.Tmp, k0, 1, w.X + (long)k0 * M, M, nbk, k0, nbk, st, -1.0, 0))) return rc;
     }
-    // Sinv = X^T X
-    return gemm1(w.Xg, 1, M, w.Xg, M, 1, w.Sinv, M, M, M, M, st);
+    if (!w.Sinv) return VGGP_OK;
+    return gemm1(w.X, 1, M, w.X, M, 1, w.Sinv, M, M, M, M, st);       // Sinv = X^T X
+}
+
+static int dense_chol_inverse(vggp_ctx* c, VgMasked& w, hipStream_t st) {
+    (void)c;
+    VgDenseChol d{w.Sg, w.Lg, w.Xg, w.DI, w.Tmp, w.cholscratch, w.choljit, w.cholstatus, w.M, w.Sinv};
+    return vg_blocked_chol_inverse(d, st);
 }
 
 extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double* W, double n_obs, double yy_obs,
