@@ -210,9 +210,11 @@ def main():
         proj_tflops = flops[proj] / (stages_us[proj] * 1e-6) / 1e12
         step_flops = sum(flops.values())
         roofline = {
-            "kernel": "vg_gemm_kernel (launch group '%s': the only pass over Y)" % proj,
+            "kernel": "vg_gemm_gram_project_kernel (launch group '%s': the only pass over Y)" % proj,
             "bound": "mfma", "achieved": proj_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": proj_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(),
+            "frac": proj_tflops / FP64_PEAK_TFLOPS,
+            "traffic": (pmc_traffic() or {}).get("bytes"),        # HBM bytes per launch (PMC passes, see traffic_source)
+            "traffic_source": pmc_traffic(),
             "flops_per_launch": flops[proj], "avg_launch_us": stages_us[proj],
             # algorithmic bytes of that launch: Y once, [B;V] of both dimensions once, un-split outputs [G;H] x2 and S
             "algorithmic_bytes_per_launch": 8 * (n1 * n2_loc + 2 * (m * n1 + m * n2_loc) + 4 * m * m + 2 * m * n1),
