@@ -386,10 +386,35 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     // with 1-4 rotations each) costs a few hundred cycles, and a round with none costs one barrier.
     const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     int rr = 0;                                    // running round count: the two counters alternate across sweep
+    // Each sweep starts with ONE scan of the strict lower triangle that flags the rounds holding a super-threshold element
+    // (pair (p, q) belongs to round (p + q) / 2 mod n1, or p when q is the resting player); only flagged rounds are
+    // visited.  What a rotation lifts above the threshold in an already passed round is caught by the next scan, and
+    // an empty scan is the convergence test -- so the tail of a warm start (a nearly empty sweep plus the verification
+    // sweep, ~230 rounds at one barrier each) costs two scans.
+    __shared__ unsigned int rmask[8];              // m2 - 1 <= 255 rounds
+    const int n1r = m2 - 1, inv2 = (n1r + 1) >> 1; // 2 * inv2 = n1r + 1 = 1 (mod n1r)
     for (int sweep = sweeps; sweep < VG_EIG_MAXSWEEP && !converged && !status; ++sweep) {      // boundaries too (m2 - 1 is odd)
         bool any = false;
-        for (int r = 0; r < m2 - 1; ++r, ++rr) {
-            const int par = rr & 1;
+        if (tid < 8) rmask[tid] = 0u;
+        vg_round_barrier<INLDS>();
+        for (int i = 1 + wave; i < m2; i += nwave) {
+            const int ti = vg_tri(i);
+            for (int j = lane; j < i; j += 64) {
+                if (fabs(W[ti + j]) > thr) {
+                    int rnd = (i == n1r) ? j : (int)(((long)(i + j) * inv2) % n1r);
+                    atomicOr(&rmask[rnd >> 5], 1u << (rnd & 31));
+                }
+            }
+        }
+        vg_round_barrier<INLDS>();
+        unsigned int mk[8];
+        bool none = true;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) { mk[w8] = rmask[w8]; none = none && mk[w8] == 0u; }
+        if (none) { ++sweeps; break; }             // uniform: every off-diagonal element is at or below the threshold
+        for (int r = 0; r < m2 - 1; ++r) {
+            if (!((mk[r >> 5] >> (r & 31)) & 1u)) continue;
+            const int par = (rr++) & 1;
 #ifdef VG_EIG_STAMP
             VG_STAMP(t0s);
 #endif
