@@ -168,3 +168,35 @@ def test_masked_grid_model_matches_dense_oracle(engine):
     assert rel(po.variance.numpy(), pd.variance.detach().numpy()) < 1e-5
     hist = model.fit(n_iter=5, lr=0.05)            # the fit loop runs and improves the bound
     assert hist[-1] < hist[0]
+
+
+def test_dense_debug_views_and_prior(engine):
+    """_Kuu / _Kuf / _sigma / prior (kept for small sizes) equal the dense restatement."""
+    from variational_gridded_gaussian_processes_amd.models import Matern12GriddedGP
+    X, y, *_ = D.gen_grid(10, 8)
+    model = Matern12GriddedGP(torch.tensor(X), torch.tensor(y), 6, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    dm = D.DenseKron(X, y, "b0", "matern12", torch.linspace(0, 1, 6), torch.linspace(0, 1, 6))
+    th = dm.theta().detach()
+    Kuu_ref = torch.kron(dm._Kuu_d(0), dm._Kuu_d(1)).detach()
+    assert rel(model._Kuu().numpy(), Kuu_ref.numpy()) < 1e-5                 # float32 k*delta of the reference mesh
+    Kuf = model._Kuf(torch.tensor(X))
+    assert Kuf.shape == (25, 80)
+    Kuf_ref = (dm._Kuf_d(0, torch.tensor(X[:, 0]))[:, None, :] * dm._Kuf_d(1, torch.tensor(X[:, 1]))[None, :, :]).reshape(25, 80).detach()
+    assert rel(Kuf.numpy(), Kuf_ref.numpy()) < 1e-5
+    S = model._sigma()
+    assert rel(S.numpy(), (Kuu_ref + Kuf_ref @ Kuf_ref.T / th[4]).numpy()) < 1e-5
+    pr = model.prior(torch.tensor(X[:7]))
+    k = th[2] * th[3] * np.exp(-abs(X[0, 0] - X[3, 0]) / th[0].item() - abs(X[0, 1] - X[3, 1]) / th[1].item())
+    assert abs(pr.covariance_matrix[0, 3].item() - float(k)) < 1e-12 and pr.mean.abs().max() == 0
+
+
+def test_not_positive_definite_raises_linalgerror(engine):
+    """ENOTPD after the jitter schedule surfaces as torch.linalg.LinAlgError (what notebook 61 cell 39 catches)."""
+    from variational_gridded_gaussian_processes_amd.models import RBFSVGP
+    X, y, *_ = D.gen_grid(12, 10)
+    z1 = np.linspace(0, 1, 8)
+    z1[3] = np.nan                                       # poisons K1: no jitter level can make it positive definite
+    Z = torch.tensor(np.stack([z1, np.linspace(0, 1, 8)], axis=1))
+    model = RBFSVGP(torch.tensor(X), torch.tensor(y), Z, engine=engine).to(torch.float64)
+    with pytest.raises(torch.linalg.LinAlgError):
+        model._elbo()

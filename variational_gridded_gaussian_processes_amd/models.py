@@ -26,6 +26,8 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
+from . import _lib
+from ._lib import VggpError
 from .engine import Engine
 
 NOISE_LOWER = 1e-4
@@ -129,7 +131,12 @@ class _ElboFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, theta: torch.Tensor, model: "KroneckerStructure"):
-        elbo, grad, info = model._engine_step([float(t) for t in theta.detach().cpu()])
+        try:
+            elbo, grad, info = model._engine_step([float(t) for t in theta.detach().cpu()])
+        except VggpError as e:
+            if e.code == _lib.VGGP_ENOTPD:       # what the reference's notebooks catch (61_envisat... cell 39)
+                raise torch.linalg.LinAlgError(str(e)) from e
+            raise
         model.last_info = info
         ctx.save_for_backward(torch.as_tensor(grad, dtype=theta.dtype, device=theta.device))
         return torch.as_tensor(elbo, dtype=theta.dtype, device=theta.device)
@@ -260,6 +267,69 @@ class KroneckerStructure(torch.nn.Module):
         """kronecker_structure.py:232-247: the likelihood adds the noise variance."""
         p = self.posterior(x_star)
         return MultivariateNormal(p.mean, p.variance + self.likelihood.noise.detach().to(p.variance.dtype))
+
+    # -- dense views kept for small sizes / debugging (the hot path never forms them) ------------------------------
+    def _factor(self, d: int, x: torch.Tensor):
+        """Unit-outputscale per-dimension factors from the engine: A0 (m x n at coordinates x), K0 (m x m)."""
+        basis, g1, g2 = self._basis()
+        ell = (self.kernel_1 if d == 0 else self.kernel_2).base_kernel.lengthscale.reshape(()).item()
+        grid = torch.as_tensor(g1 if d == 0 else g2, dtype=torch.float64, device=self._engine.device)
+        xs = torch.as_tensor(x, dtype=torch.float64, device=self._engine.device).contiguous()
+        flags = 1 if (basis == "b0" and self._f32_mesh()) else 0
+        A, _, K, _ = self._engine.factor_build(self.kind, basis, xs, grid, ell, flags)
+        return A, K
+
+    def _Kuu_along_dim(self, d: int) -> torch.Tensor:
+        """kronecker_structure.py:702-739 (B0) / :318-319 (points): m_d x m_d, outputscale applied (no jitter)."""
+        s = (self.kernel_1 if d == 0 else self.kernel_2).outputscale.detach().to(torch.float64)
+        _, K = self._factor(d, torch.zeros(1, dtype=torch.float64))
+        return (s.to(K.device) * K).cpu()
+
+    def _Kuf_along_dim(self, d: int, x: torch.Tensor) -> torch.Tensor:
+        """kronecker_structure.py:741-790 (B0) / :336-337 (points): m_d x len(x)."""
+        s = (self.kernel_1 if d == 0 else self.kernel_2).outputscale.detach().to(torch.float64)
+        A, _ = self._factor(d, x)
+        return (s.to(A.device) * A).cpu()
+
+    def _Kuu(self) -> torch.Tensor:
+        """kronecker_structure.py:792-806: torch.kron(Kuu_1, Kuu_2), M x M dense -- small M only."""
+        K1, K2 = self._Kuu_along_dim(0), self._Kuu_along_dim(1)
+        if K1.shape[0] * K2.shape[0] > 8192:
+            raise ValueError("_Kuu(): M = m1*m2 > 8192; the dense matrix is for small sizes / debugging only")
+        return torch.kron(K1, K2)
+
+    def _Kuf(self, x: torch.Tensor) -> torch.Tensor:
+        """kronecker_structure.py:808-823: row-wise Khatri-Rao of the per-dimension factors, M x N, u = i1*m2 + i2."""
+        x = torch.as_tensor(x, dtype=torch.float64)
+        A1, A2 = self._Kuf_along_dim(0, x[:, 0]), self._Kuf_along_dim(1, x[:, 1])
+        if A1.shape[0] * A2.shape[0] * x.shape[0] > (1 << 27):
+            raise ValueError("_Kuf(): M*N too large for the dense matrix (small sizes / debugging only)")
+        return (A1[:, None, :] * A2[None, :, :]).reshape(-1, x.shape[0])
+
+    def _sigma(self) -> torch.Tensor:
+        """kronecker_structure.py:134-150: Kuu + Kuf Kuf^T / sigma^2 (dense; debugging only)."""
+        Kuf = self._Kuf(self.train_inputs[0])
+        return self._Kuu() + Kuf @ Kuf.T / self.likelihood.noise.detach().to(torch.float64).cpu()
+
+    def prior(self, x: torch.Tensor) -> MultivariateNormal:
+        """kronecker_structure.py:90-103: zero mean, product kernel k1(x1,x1') k2(x2,x2') -- dense N x N, small N only."""
+        x = torch.as_tensor(x, dtype=torch.float64)
+        if x.shape[0] > 8192:
+            raise ValueError("prior(): dense N x N covariance, N <= 8192")
+        cov = torch.ones(x.shape[0], x.shape[0], dtype=torch.float64)
+        for d, k in ((0, self.kernel_1), (1, self.kernel_2)):
+            r = (x[:, d, None] - x[None, :, d]).abs() / k.base_kernel.lengthscale.reshape(()).item()
+            kind = k.base_kernel.kind
+            if kind == "matern12":
+                kd = torch.exp(-r)
+            elif kind == "matern32":
+                kd = (1 + math.sqrt(3) * r) * torch.exp(-math.sqrt(3) * r)
+            elif kind == "matern52":
+                kd = (1 + math.sqrt(5) * r + 5 * r * r / 3) * torch.exp(-math.sqrt(5) * r)
+            else:
+                kd = torch.exp(-0.5 * r * r)
+            cov = cov * k.outputscale.detach().to(torch.float64) * kd
+        return MultivariateNormal(torch.zeros(x.shape[0], dtype=torch.float64), torch.diagonal(cov).clone(), cov_fn=lambda: cov)
 
     def non_informative_initialise(self, lmbda: float, kappa: float) -> None:
         """kronecker_structure.py:34-61.  As in the reference, the `lengthscale[0] = ...` assignments go
