@@ -99,9 +99,33 @@ def cpu_baseline(n1, n2, m, kind, theta, budget_s=15.0):
     except Exception:
         cores = os.cpu_count()
     return {"value": n1 * n2 / dt, "unit": "grid-points/s", "cores": int(cores), "kind": "port",
+            "dense_reference_literal": dense_literal_timing(kind, theta),
             "ms_per_step": dt * 1e3,
             "sample": f"{steps} ELBO steps (value+analytic gradient) of oracle/kron.py (numpy/LAPACK float64) on the "
                       f"same {n2}x{n1} {kind} grid, m_d={m}"}
+
+
+def dense_literal_timing(kind, theta):
+    """The reference's own dense algebra (oracle/dense.py: three N x N matrices, O(N^3) Cholesky, autograd backward) at the
+    sizes it can run, with the N^3 extrapolation to the workload -- it cannot run at 256^2 and beyond (3 x 34 GB there)."""
+    try:
+        import torch
+        from oracle import dense as D
+        out = {}
+        for n in (16, 32, 48):            # 16: warm-up of the BLAS / autograd machinery, not reported
+            X, y, x1, x2 = D.gen_grid(n, n)
+            g = torch.tensor(np.linspace(0, 1, 8))
+            dm = D.DenseKron(X, y, "points", kind, g, g, raw=D.raw_from_constrained(list(theta)))
+            t0 = time.perf_counter()
+            dm.elbo_and_grad()
+            if n > 16:
+                out[f"{n}x{n}_s"] = time.perf_counter() - t0
+        n_ref = 48
+        out["extrapolated_1024x1024_s"] = out[f"{n_ref}x{n_ref}_s"] * ((1024 * 1024) / (n_ref * n_ref)) ** 3
+        out["note"] = "value + autograd gradient, m_d = 8; N^3 extrapolation from 48x48"
+        return out
+    except Exception as e:          # never let the optional extra break the bench line
+        return {"error": str(e)}
 
 
 def main():
