@@ -68,10 +68,10 @@ def algorithmic_flops(n1, n2, m1, m2):
     """Per-rank flops of one step by launch group (dense-contraction counts)."""
     f = {}
     f["gemm_BV(Linv*[A|dA])"] = 2 * (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2) + 2 * (m1 ** 3 + m2 ** 3)
-    f["gemm_gram+project(S=[B2;V2]Y)"] = (2 * 2 * m2 * n1 * n2            # S^T = [B2;V2] Y  (the only pass over Y)
-                                          + 2 * (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2)   # [G;H] = [B;V] B^T
-                                          + 2 * (m1 ** 3 + m2 ** 3))                    # Mk
-    f["gemm_C(B1*S)"] = 2 * 3 * m1 * m2 * n1
+    f["gemm_gram+project(S=[B2;V2]Y)"] = 2 * 2 * m2 * n1 * n2                 # S = [B2;V2] Y  (the only pass over Y)
+    f["gemm_C(B1*S)"] = (2 * 3 * m1 * m2 * n1                               # [C;C1;C2]
+                         + 2 * (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2)           # [G;H] = [B;V] B^T, both dimensions
+                         + 2 * (m1 ** 3 + m2 ** 3))                            # Mk
     f["gemm_rotate_right"] = 2 * 2 * (m1 ** 3 + m2 ** 3) + 2 * 3 * m1 * m2 * m2
     f["gemm_rotate_left"] = 2 * 2 * (m1 ** 3 + m2 ** 3) + 2 * 3 * m1 * m1 * m2
     f["gemm_betaGram"] = 2 * 2 * (m1 * m1 * m2 + m2 * m2 * m1)
@@ -240,8 +240,8 @@ def main():
             "traffic": (pmc_traffic() or {}).get("bytes"),        # HBM bytes per launch (PMC passes, see traffic_source)
             "traffic_source": pmc_traffic(),
             "flops_per_launch": flops[proj], "avg_launch_us": stages_us[proj],
-            # algorithmic bytes of that launch: Y once, [B;V] of both dimensions once, un-split outputs [G;H] x2 and S
-            "algorithmic_bytes_per_launch": 8 * (n1 * n2_loc + 2 * (m * n1 + m * n2_loc) + 4 * m * m + 2 * m * n1),
+            # algorithmic bytes of that launch: Y once, [B2;V2] once, the un-split output S
+            "algorithmic_bytes_per_launch": 8 * (n1 * n2_loc + 2 * m * n2_loc + 2 * m * n1),
             "dominant_stage_by_time": dom, "dominant_stage_us": stages_us[dom],
             "step_dense_flops": step_flops,
             "step_frac_of_fp64_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

@@ -331,14 +331,12 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(3);
 
-    // 4. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T, S^T = [B2;V2] Y (split-K slabs)
+    // 4. S = [B2;V2] Y (split-K slabs): the only pass over Y.  Exactly tiles x splits = one workgroup per CU at the
+    //    headline size, so the Gram pairs that used to share this launch now ride in the next one (whose own products
+    //    fill less than half the chip): two workgroups on one CU halve each other's MFMA rate.
     vg_gemm_init(&g);
-    for (int k = 0; k < 2; ++k) {
-        VgDim& d = c->d[k];
-        vg_gemm_add(&g, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
-        vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
-    }
     vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
+    const int st_slabs = g.p[0].ksplit;
     if (extrap)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
@@ -347,16 +345,23 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         }
     VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_GRAM_PROJECT));
     VG_MARK(4);
-    const int st_slabs = g.p[4].ksplit;
-    const int gh_slabs[2] = {g.p[0].ksplit, g.p[2].ksplit};
 
-    // 5. [C;C1] = [B1;V1] S_B,  C2 = B1 S_V   (S^T slabs summed on load; split-K over n1)
+    // 5. [C;C1] = [B1;V1] S_B,  C2 = B1 S_V   (S slabs summed on load; split-K over n1),
+    //    Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T
     vg_gemm_init(&g);
     const long cc_slab = 3L * m1 * m2;
     vg_gemm_add(&g, d1.BV, n1, 1, c->St, 1, n1, c->CCslab, (int)m2, (int)(2 * m1), (int)m2, (int)n1, c->cc_split, cc_slab,
                 st_slabs, 2L * m2 * n1);
     vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
                 c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
+    const int cc_slabs = g.p[0].ksplit;
+    int gh_slabs[2] = {1, 1};
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        const int ig = vg_gemm_add(&g, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
+        gh_slabs[k] = g.p[ig].ksplit;
+        vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
+    }
     if (extrap)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
@@ -364,7 +369,6 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         }
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(5);
-    const int cc_slabs = g.p[0].ksplit;
 
     c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs;
     // 6. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}.  Skipped inside a fused
