@@ -152,11 +152,78 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
         }
         __syncthreads();
     };
-    if (k_begin < k_end) load_tile(k_begin, ra0, rb0);
-    if (k_begin + BK < k_end) load_tile(k_begin + BK, ra1, rb1);
-    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
-        ktile(ra0, rb0, k0 + 2 * BK);
-        if (k0 + BK < k_end) ktile(ra1, rb1, k0 + 3 * BK);
+    // Interior tiles with whole k-tiles and plain operands (every hot shape of the step) take a branch-free loop: element
+    // pointers advance by one add per k-tile and the loads carry no predicate.  (The generic loop's `ok ? *p : 0` loads
+    // compile to an exec-mask branch region each -- ~150 branches per k-tile pair -- and bound it by instruction issue.)
+    // (slab operands: only for the short m x m x m products -- measured: the long split-K consumer [C;C1] = [B1;V1] S is
+    // faster through the generic loop, 22 vs 31 us)
+    const bool fast = row0 + T <= M && col0 + T <= N && k_begin < k_end && ((k_end - k_begin) % BK) == 0 &&
+                      ((nslab == 1 && anslab == 1) || p.K <= 512);
+    if (fast) {
+        const double* pa[4];
+        const double* pb[4];
+        int la[4], lb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pa[r] = A + (long)(row0 + a_i[r]) * sa_m + (long)(k_begin + a_k[r]) * sa_k;
+            pb[r] = B + (long)(k_begin + b_k[r]) * sb_k + (long)(col0 + b_j[r]) * sb_n;
+            la[r] = a_i[r] * a_si + a_k[r] * a_sk;
+            lb[r] = b_k[r] * b_sk + b_j[r] * b_sj;
+        }
+        const long da = (long)BK * sa_k, db = (long)BK * sb_k;
+        const int nk = (k_end - k_begin) / BK;
+        auto ld = [&](double (&ra)[4], double (&rb)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ra[r] = *pa[r]; rb[r] = *pb[r]; }
+            // operands given as split-K slabs of their producer: three further slabs (12 loads) in flight per round trip
+            for (int sl = 1; sl < nslab; sl += 3) {
+                const long o0 = (long)sl * bslab, o1 = sl + 1 < nslab ? o0 + bslab : o0, o2 = sl + 2 < nslab ? o0 + 2 * bslab : o0;
+                const double w1 = sl + 1 < nslab ? 1.0 : 0.0, w2 = sl + 2 < nslab ? 1.0 : 0.0;      // uniform
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rb[r] += (pb[r][o0] + w1 * pb[r][o1]) + w2 * pb[r][o2];
+            }
+            for (int sl = 1; sl < anslab; sl += 3) {
+                const long o0 = (long)sl * aslab, o1 = sl + 1 < anslab ? o0 + aslab : o0, o2 = sl + 2 < anslab ? o0 + 2 * aslab : o0;
+                const double w1 = sl + 1 < anslab ? 1.0 : 0.0, w2 = sl + 2 < anslab ? 1.0 : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ra[r] += (pa[r][o0] + w1 * pa[r][o1]) + w2 * pa[r][o2];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pa[r] += da; pb[r] += db; }
+        };
+        auto kt = [&](double (&ra)[4], double (&rb)[4], bool more) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { As[la[r]] = ra[r]; Bs[lb[r]] = rb[r]; }
+            __syncthreads();
+            if (more) ld(ra, rb);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                double av[MB], bv[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[mb] = As[(wr * WT + mb * 16 + fi) * a_si + (kk + fk) * a_sk];
+#pragma unroll
+                for (int nb = 0; nb < MB; ++nb) bv[nb] = Bs[(kk + fk) * b_sk + (wc * WT + nb * 16 + fi) * b_sj];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < MB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+            }
+            __syncthreads();
+        };
+        ld(ra0, rb0);
+        if (nk > 1) ld(ra1, rb1);
+        for (int it = 0; it < nk; it += 2) {
+            kt(ra0, rb0, it + 2 < nk);
+            if (it + 1 < nk) kt(ra1, rb1, it + 3 < nk);
+        }
+    } else {
+        if (k_begin < k_end) load_tile(k_begin, ra0, rb0);
+        if (k_begin + BK < k_end) load_tile(k_begin + BK, ra1, rb1);
+        for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+            ktile(ra0, rb0, k0 + 2 * BK);
+            if (k0 + BK < k_end) ktile(ra1, rb1, k0 + 3 * BK);
+        }
     }
 
     double* __restrict__ C = p.C + (long)ks * p.c_slab;
