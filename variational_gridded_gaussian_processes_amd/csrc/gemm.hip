@@ -18,6 +18,8 @@
 //                           two k rows of a 32-lane LDS group use disjoint bank halves)
 #include "common.h"
 
+#include <cstdlib>
+
 typedef double vg_d4 __attribute__((ext_vector_type(4)));
 
 // Tile configurations: <T = 64, BK = 16> for the contractions over the grid (MFMA-bound: 16 MFMAs per wave and k-tile),
@@ -32,10 +34,13 @@ struct VgTile {
     static constexpr int MB = T / 32;                        // 16 x 16 MFMA blocks per wave and dimension
 };
 
-template <int T, int BK>
+template <int T, int BK, int NT = 256>
 __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) {
     using C_ = VgTile<T, BK>;
-    constexpr int MB = C_::MB;
+    constexpr int NR = T * BK / NT;                              // elements per thread, operand and k-tile
+    constexpr int WC = NT / 128;                                 // wave grid 2 x WC
+    constexpr int MB = T / 32;                                   // 16 x 16 MFMA blocks per wave: rows
+    constexpr int NB = T / (16 * WC);                            //                               columns
     double* As = lds;
     double* Bs = lds + C_::TILE;
 
@@ -56,7 +61,7 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
 
     const double* __restrict__ A = p.A;
     const double* __restrict__ B = p.B;
@@ -68,26 +73,26 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
     const long bslab = p.b_slab, aslab = p.a_slab;
 
     // global->register mapping for the T x BK A tile and BK x T B tile: 4 elements each
-    int a_i[4], a_k[4], b_k[4], b_j[4];
+    int a_i[NR], a_k[NR], b_k[NR], b_j[NR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (a_kc) { a_k[r] = tid % BK; a_i[r] = tid / BK + (256 / BK) * r; }
-        else      { a_i[r] = tid % T; a_k[r] = tid / T + (256 / T) * r; }
-        if (b_nc) { b_j[r] = tid % T; b_k[r] = tid / T + (256 / T) * r; }
-        else      { b_k[r] = tid % BK; b_j[r] = tid / BK + (256 / BK) * r; }
+    for (int r = 0; r < NR; ++r) {
+        if (a_kc) { a_k[r] = tid % BK; a_i[r] = tid / BK + (NT / BK) * r; }
+        else      { a_i[r] = tid % T; a_k[r] = tid / T + (NT / T) * r; }
+        if (b_nc) { b_j[r] = tid % T; b_k[r] = tid / T + (NT / T) * r; }
+        else      { b_k[r] = tid % BK; b_j[r] = tid / BK + (NT / BK) * r; }
     }
     const int a_si = a_kc ? C_::RS : 1, a_sk = a_kc ? 1 : C_::KS;
     const int b_sj = b_nc ? 1 : C_::RS, b_sk = b_nc ? C_::KS : 1;
 
     // two register stages: while tile i is multiplied, tiles i+1 AND i+2 are in flight (one k-tile of MFMAs is ~0.5 us,
     // an L2 / HBM round trip is 1-2 us: a single stage leaves every k-tile waiting for its operands)
-    double ra0[4], rb0[4], ra1[4], rb1[4];
-    auto load_tile = [&](int k0, double (&ra)[4], double (&rb)[4]) {
-        const double* bp[4];
-        const double* ap[4];
-        bool bok[4], aok[4];
+    double ra0[NR], rb0[NR], ra1[NR], rb1[NR];
+    auto load_tile = [&](int k0, double (&ra)[NR], double (&rb)[NR]) {
+        const double* bp[NR];
+        const double* ap[NR];
+        bool bok[NR], aok[NR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int gi = row0 + a_i[r], gk = k0 + a_k[r];
             aok[r] = gi < M && gk < k_end;
             ap[r] = A + (aok[r] ? gi * sa_m + gk * sa_k : 0);
@@ -100,36 +105,36 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
         // B given as a sum of slabs (the producer's split-K partials): all 4 elements of up to 3 further slabs are
         // in flight together -- a load-add chain per slab would expose one L2 round trip per slab and element
         for (int s = 1; s < nslab; s += 3) {
-            double t[3][4];
+            double t[3][NR];
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[u][r] = (bok[r] && s + u < nslab) ? bp[r][(long)(s + u) * bslab] : 0.0;
+                for (int r = 0; r < NR; ++r) t[u][r] = (bok[r] && s + u < nslab) ? bp[r][(long)(s + u) * bslab] : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rb[r] += (t[0][r] + t[1][r]) + t[2][r];
+            for (int r = 0; r < NR; ++r) rb[r] += (t[0][r] + t[1][r]) + t[2][r];
         }
         for (int s = 1; s < anslab; s += 3) {
-            double t[3][4];
+            double t[3][NR];
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[u][r] = (aok[r] && s + u < anslab) ? ap[r][(long)(s + u) * aslab] : 0.0;
+                for (int r = 0; r < NR; ++r) t[u][r] = (aok[r] && s + u < anslab) ? ap[r][(long)(s + u) * aslab] : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ra[r] += (t[0][r] + t[1][r]) + t[2][r];
+            for (int r = 0; r < NR; ++r) ra[r] += (t[0][r] + t[1][r]) + t[2][r];
         }
     };
 
-    vg_d4 acc[MB][MB];
+    vg_d4 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < MB; ++j) acc[i][j] = (vg_d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NB; ++j) acc[i][j] = (vg_d4){0.0, 0.0, 0.0, 0.0};
 
     const int fi = lane & 15, fk = lane >> 4;
-    constexpr int WT = T / 2;                                  // rows / cols per wave
-    auto ktile = [&](double (&ra)[4], double (&rb)[4], int knext) {
+    constexpr int WT = T / 2, WTC = T / WC;                    // rows / cols per wave
+    auto ktile = [&](double (&ra)[NR], double (&rb)[NR], int knext) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             As[a_i[r] * a_si + a_k[r] * a_sk] = ra[r];
             Bs[b_k[r] * b_sk + b_j[r] * b_sj] = rb[r];
         }
@@ -137,17 +142,17 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
         if (knext < k_end) load_tile(knext, ra, rb);           // refill this stage: two k-tiles ahead
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
-            double av[MB], bv[MB];
+            double av[MB], bv[NB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
                 av[mb] = As[(wr * WT + mb * 16 + fi) * a_si + (kk + fk) * a_sk];
 #pragma unroll
-            for (int nb = 0; nb < MB; ++nb)
-                bv[nb] = Bs[(kk + fk) * b_sk + (wc * WT + nb * 16 + fi) * b_sj];
+            for (int nb = 0; nb < NB; ++nb)
+                bv[nb] = Bs[(kk + fk) * b_sk + (wc * WTC + nb * 16 + fi) * b_sj];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < MB; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
         }
         __syncthreads();
@@ -160,11 +165,11 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
     const bool fast = row0 + T <= M && col0 + T <= N && k_begin < k_end && ((k_end - k_begin) % BK) == 0 &&
                       ((nslab == 1 && anslab == 1) || p.K <= 512);
     if (fast) {
-        const double* pa[4];
-        const double* pb[4];
-        int la[4], lb[4];
+        const double* pa[NR];
+        const double* pb[NR];
+        int la[NR], lb[NR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             pa[r] = A + (long)(row0 + a_i[r]) * sa_m + (long)(k_begin + a_k[r]) * sa_k;
             pb[r] = B + (long)(k_begin + b_k[r]) * sb_k + (long)(col0 + b_j[r]) * sb_n;
             la[r] = a_i[r] * a_si + a_k[r] * a_sk;
@@ -172,41 +177,41 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
         }
         const long da = (long)BK * sa_k, db = (long)BK * sb_k;
         const int nk = (k_end - k_begin) / BK;
-        auto ld = [&](double (&ra)[4], double (&rb)[4]) {
+        auto ld = [&](double (&ra)[NR], double (&rb)[NR]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ra[r] = *pa[r]; rb[r] = *pb[r]; }
+            for (int r = 0; r < NR; ++r) { ra[r] = *pa[r]; rb[r] = *pb[r]; }
             // operands given as split-K slabs of their producer: three further slabs (12 loads) in flight per round trip
             for (int sl = 1; sl < nslab; sl += 3) {
                 const long o0 = (long)sl * bslab, o1 = sl + 1 < nslab ? o0 + bslab : o0, o2 = sl + 2 < nslab ? o0 + 2 * bslab : o0;
                 const double w1 = sl + 1 < nslab ? 1.0 : 0.0, w2 = sl + 2 < nslab ? 1.0 : 0.0;      // uniform
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rb[r] += (pb[r][o0] + w1 * pb[r][o1]) + w2 * pb[r][o2];
+                for (int r = 0; r < NR; ++r) rb[r] += (pb[r][o0] + w1 * pb[r][o1]) + w2 * pb[r][o2];
             }
             for (int sl = 1; sl < anslab; sl += 3) {
                 const long o0 = (long)sl * aslab, o1 = sl + 1 < anslab ? o0 + aslab : o0, o2 = sl + 2 < anslab ? o0 + 2 * aslab : o0;
                 const double w1 = sl + 1 < anslab ? 1.0 : 0.0, w2 = sl + 2 < anslab ? 1.0 : 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ra[r] += (pa[r][o0] + w1 * pa[r][o1]) + w2 * pa[r][o2];
+                for (int r = 0; r < NR; ++r) ra[r] += (pa[r][o0] + w1 * pa[r][o1]) + w2 * pa[r][o2];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pa[r] += da; pb[r] += db; }
+            for (int r = 0; r < NR; ++r) { pa[r] += da; pb[r] += db; }
         };
-        auto kt = [&](double (&ra)[4], double (&rb)[4], bool more) {
+        auto kt = [&](double (&ra)[NR], double (&rb)[NR], bool more) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { As[la[r]] = ra[r]; Bs[lb[r]] = rb[r]; }
+            for (int r = 0; r < NR; ++r) { As[la[r]] = ra[r]; Bs[lb[r]] = rb[r]; }
             __syncthreads();
             if (more) ld(ra, rb);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
-                double av[MB], bv[MB];
+                double av[MB], bv[NB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) av[mb] = As[(wr * WT + mb * 16 + fi) * a_si + (kk + fk) * a_sk];
 #pragma unroll
-                for (int nb = 0; nb < MB; ++nb) bv[nb] = Bs[(kk + fk) * b_sk + (wc * WT + nb * 16 + fi) * b_sj];
+                for (int nb = 0; nb < NB; ++nb) bv[nb] = Bs[(kk + fk) * b_sk + (wc * WTC + nb * 16 + fi) * b_sj];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < MB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
             }
             __syncthreads();
@@ -231,11 +236,11 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < MB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + wr * WT + mb * 16 + fk + 4 * r;
-                const int col = col0 + wc * WT + nb * 16 + fi;
+                const int col = col0 + wc * WTC + nb * 16 + fi;
                 if (row < M && col < N) {
                     double* cp = C + (long)row * ldc + col;
                     const double v = p.alpha * acc[mb][nb][r];
@@ -253,6 +258,12 @@ __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
 __global__ __launch_bounds__(256) void vg_gemm_gram_project_kernel(const VgGemmBatch b) {
     __shared__ double lds[2 * VgTile<64, 16>::TILE];
     vg_gemm_body<64, 16>(b, lds);
+}
+// same tile with 8 waves (2 per SIMD): used when a launch has about one workgroup per CU, where a single wave per SIMD
+// leaves the MFMA pipe idle between its own LDS round trips and barriers
+__global__ __launch_bounds__(512) void vg_gemm_gram_project_wide_kernel(const VgGemmBatch b) {
+    __shared__ double lds[2 * VgTile<64, 16>::TILE];
+    vg_gemm_body<64, 16, 512>(b, lds);
 }
 __global__ __launch_bounds__(256) void vg_gemm_small_kernel(const VgGemmBatch b) {
     __shared__ double lds[2 * VgTile<32, 32>::TILE];
@@ -313,7 +324,10 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
         hipLaunchKernelGGL(vg_gemm_small_kernel, dim3(s.total_tiles), dim3(256), 0, st, s);
         return hipGetLastError();
     }
-    if (tag == VG_GEMM_TAG_GRAM_PROJECT)
+    static const bool wide = getenv("VGGP_GEMM_NARROW") == nullptr;
+    if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && b->total_tiles <= 320)
+        hipLaunchKernelGGL(vg_gemm_gram_project_wide_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
+    else if (tag == VG_GEMM_TAG_GRAM_PROJECT)
         hipLaunchKernelGGL(vg_gemm_gram_project_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
     else
         hipLaunchKernelGGL(vg_gemm_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
