@@ -230,3 +230,29 @@ def test_config5_shape_masked_b0_vs_structured_oracle(engine):
     mean, var = engine.qv_masked()
     rm, rv = Kr.q_v_masked(ref)
     assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-6
+
+
+def test_failed_step_resets_the_warm_start(engine):
+    """A step that fails (NaN data -> not positive definite is not reachable from data, so poison the grid instead) must
+    not leave its bases behind: the following valid steps start cold and are correct."""
+    n1, n2, m = 40, 36, 8
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    g = np.linspace(0, 1, m)
+    f1, f2 = Kr.Factor("points", "rbf", g, x1), Kr.Factor("points", "rbf", g, x2)
+    theta = [0.3, 0.25, 0.9, 1.2, 0.01]
+    ref = Kr.elbo_step(y.reshape(n2, n1), f1, f2, theta)
+    engine.plan("rbf", "points", g, x1, "rbf", "points", g, x2, warm_start=True)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    yy = engine.sumsq(Y)
+    for _ in range(3):
+        engine.elbo_step(Y, yy, theta)
+    Ybad = Y.clone()
+    Ybad[3, 4] = float("nan")
+    from variational_gridded_gaussian_processes_amd import VggpError
+    try:
+        engine.elbo_step(Ybad, yy, theta)          # NaN propagates into G?  (G depends on the factors only) -> may succeed
+    except VggpError:
+        pass
+    for _ in range(3):
+        elbo, grad, info = engine.elbo_step(Y, yy, theta)
+        assert abs(elbo - ref.elbo) <= 1e-9 * abs(ref.elbo) and rel(grad, ref.grad) < 1e-7

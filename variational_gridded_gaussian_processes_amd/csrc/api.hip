@@ -167,6 +167,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.Qt = b.take<double>(m * m);
         d.QtPrev = b.take<double>(m * m);
         d.QtPrev2 = b.take<double>(m * m);
+        d.U = b.take<double>(m * m);
         d.Gw = b.take<double>(m * m);
         d.GH = b.take<double>(2 * m * m);
         d.Mk = b.take<double>(m * m);
@@ -317,16 +318,17 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
             vg_gemm_add(&g, d.Linv0, d.m, 1, d.AD + b * mn, d.n, 1, d.BV + b * mn, d.n, d.m, d.n, d.m);
         vg_gemm_add(&g, d.Linv0, d.m, 1, d.dK0, d.m, 1, d.X, d.m, d.m, d.m, d.m);
     }
-    // extrapolated warm start (rides in this and the next launch, no launch of its own): the basis moved from Q(t-2) to
-    // Q(t-1) by the rotation Q(t-1) Q(t-2)^T; applying it once more predicts this step's basis,
-    //     Qpred = Q(t-1) Q(t-2)^T Q(t-1)          (rows = eigenvectors; U -> TH, Qpred -> E, all free until after eigh)
+    // extrapolated warm start, riding in launches that exist anyway: the basis moved from Q(t-2) to Q(t-1) by the rotation
+    // U = Q(t-1) Q(t-2)^T (formed in the LAST launch group of the previous step); applying it once more predicts this
+    // step's basis, Qpred = U Q(t-1) (rows = eigenvectors; Qpred -> E, 1.5 Qpred -> F, free until after eigh).
     // A product of three bases triples their departure from orthogonality and feeds it back into the next bases -- it
     // would grow ~2.4x per step -- so one Newton-Schulz step follows: Q' = 1.5 Qpred - 0.5 (Qpred Qpred^T) Qpred
-    // (1.5 Qpred -> F here, W = Qpred Qpred^T -> TH in the next launch, the last product at the start of the finish).
+    // (W = Qpred Qpred^T -> TH in the next launch, F += -0.5 W Qpred in the one after).
     if (extrap)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.TH, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.U, d.m, 1, d.QtPrev, d.m, 1, d.E, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.U, d.m, 1, d.QtPrev, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 1.5, 0);
         }
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(3);
@@ -340,8 +342,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     if (extrap)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.TH, d.m, 1, d.QtPrev, d.m, 1, d.E, d.m, d.m, d.m, d.m);
-            vg_gemm_add(&g, d.TH, d.m, 1, d.QtPrev, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 1.5, 0);
+            vg_gemm_add(&g, d.E, d.m, 1, d.E, 1, d.m, d.TH, d.m, d.m, d.m, d.m);      // W = Qpred Qpred^T
         }
     VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_GRAM_PROJECT));
     VG_MARK(4);
@@ -365,7 +366,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     if (extrap)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.E, d.m, 1, d.E, 1, d.m, d.TH, d.m, d.m, d.m, d.m);      // W = Qpred Qpred^T
+            vg_gemm_add(&g, d.TH, d.m, 1, d.E, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);   // Newton-Schulz
         }
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(5);
@@ -404,14 +405,6 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
     VgEigJob ej[2];
-    if (warm && extrap) {          // Newton-Schulz: F = 1.5 Qpred - 0.5 W Qpred, the orthonormal start basis
-        vg_gemm_init(&g);
-        for (int k = 0; k < 2; ++k) {
-            VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.TH, d.m, 1, d.E, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
-        }
-        VG_HIP(vg_gemm_launch(&g, st));
-    }
     if (warm) {
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
@@ -482,6 +475,11 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
     vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
     vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
+    if (warm && c->desc.warm_start)      // U = Q(t) Q(t-1)^T for the NEXT step's extrapolated start (both bases are final here)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.U, d.m, d.m, d.m, d.m);
+        }
     VG_HIP(vg_gemm_launch(&g, st));
     VG_MARK(13);
     VG_HIP(vg_final_launch(&ms, st));
@@ -563,6 +561,11 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         info->sweeps1 = c->h_out->counters[0][1]; info->sweeps2 = c->h_out->counters[1][1];
         info->rounds1 = c->h_out->counters[0][0]; info->rounds2 = c->h_out->counters[1][0];
         info->status = status; info->reserved = 0;
+    }
+    if (status) {          // the bases written by this step are not trustworthy: the next step starts cold
+        c->warm_run = 0;
+        for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+        c->have_step = false;
     }
     if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
     if (status == VGGP_ENOCONV) { vg_set_error("Jacobi eigensolver did not converge"); return VGGP_ENOCONV; }

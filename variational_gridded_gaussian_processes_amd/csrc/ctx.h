@@ -7,7 +7,7 @@ struct VgDim {
     double *x = nullptr, *grid = nullptr;
     double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
     double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
-    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr, *QtPrev2 = nullptr;
+    double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr, *QtPrev2 = nullptr, *U = nullptr;
     double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
     double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
     double2* rotlog = nullptr;
