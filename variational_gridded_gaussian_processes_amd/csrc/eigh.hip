@@ -326,6 +326,12 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
     return Wfin;
 }
 
+#ifdef VG_EIG_RT
+#define RT(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); reinterpret_cast<unsigned long long*>(J.gwork)[256 + (i)] = t_; } } while (0)
+#else
+#define RT(i)
+#endif
+
 template <bool INLDS>
 __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, VgActRec* actrec, unsigned char* isact,
                                int* nact_s, double* red, bool fast) {
@@ -334,14 +340,36 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int tx = tid & 31, ty = tid >> 5, nty = nthr >> 5;
 
+    RT(0);
     // load the lower triangle (zero padded) and the Frobenius norm
+    // (a wave takes whole rows -- coalesced, no integer division -- and four rows' loads are in flight together)
     double ss = 0.0;
-    for (int idx = tid; idx < m2 * m2; idx += nthr) {
-        const int i = idx / m2, j = idx - i * m2;
-        if (j > i) continue;
-        const double v = (i < m && j < m) ? J.G[i * m + j] : 0.0;
-        W[vg_tri(i) + j] = v;
-        ss += (i == j) ? v * v : 2.0 * v * v;
+    {
+        const int lane_ = tid & 63, wave_ = tid >> 6, nw_ = nthr >> 6;
+        for (int i0 = wave_; i0 < m2; i0 += 4 * nw_) {
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nw_;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int j = lane_ + 64 * h;
+                    v[u][h] = (i < m && j <= i && j < m) ? J.G[i * m + j] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nw_;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int j = lane_ + 64 * h;
+                    if (i < m2 && j <= i) {
+                        W[vg_tri(i) + j] = v[u][h];
+                        ss += (i == j) ? v[u][h] * v[u][h] : 2.0 * v[u][h] * v[u][h];
+                    }
+                }
+            }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
@@ -353,10 +381,12 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
     int nlog = 0, sweeps = 0, status = 0;
     bool converged = false;
+    RT(1);
     if (INLDS && fast)           // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
         W = vg_jacobi_fast(J, W, W + ((m2 * (m2 + 1)) >> 1), cs, reinterpret_cast<double*>(pq), nact_s, thr, nlog, sweeps,
                            status, converged);
 
+    RT(2);
     // round-independent block -> thread map: canonical blocks (al >= be) enumerated row by row, dealt round-robin
     int my_al[VG_MAXMINE], my_be[VG_MAXMINE];
     int nmine = 0;
@@ -503,6 +533,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
         if (status || !any) break;
         if (sweep == VG_EIG_MAXSWEEP - 1) status = VGGP_ENOCONV;
     }
+    RT(3);
     // every storing wave drains its log stores BEFORE the barrier that precedes the DONE publication
     // (__syncthreads() alone does not wait for vmcnt on gfx950)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -511,13 +542,17 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     // this basis, and cyclic Jacobi on the strongly graded Gram matrices converges in fewer sweeps when the diagonal is
     // ordered (RBF, m = 128, 1% hyper-parameter change: 5 rotating sweeps instead of 6-7; unordered bases are what a
     // Jacobi solver leaves behind).  The replay workgroups permute their rows of Q^T with the same ranks.
+    double* dg = reinterpret_cast<double*>(cs);         // the diagonal, staged contiguously (the rotation array is free now)
+    for (int i = tid; i < m; i += nthr) dg[i] = W[vg_tri(i) + i];
+    __syncthreads();
     for (int i = tid; i < m; i += nthr) {
-        const double li = W[vg_tri(i) + i];
+        const double li = dg[i];
         int rank = i;
         if (J.perm) {
             rank = 0;
+#pragma unroll 8
             for (int j = 0; j < m; ++j) {
-                const double lj = W[vg_tri(j) + j];
+                const double lj = dg[j];
                 rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
             }
             __hip_atomic_store(&J.perm[i], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -533,6 +568,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    RT(4);
 #ifdef VG_EIG_STAMP
     if ((tid & 63) == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(J.gwork) + (tid >> 6) * 4;
@@ -579,7 +615,7 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
             for (;;) {
                 pw = __hip_atomic_load(&J.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int avail = (pw & (VG_EIG_DONE - 1)) - consumed;
-                if ((pw & VG_EIG_DONE) || avail >= rounds_per_chunk || avail >= 32) break;
+                if ((pw & VG_EIG_DONE) || avail >= rounds_per_chunk || avail >= 8) break;      // small batches: short tail after DONE
                 if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; break; }   // bounded spin: never hang the GPU
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -651,6 +687,10 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
             if (J.Qt2) J.Qt2[di * m + j] = v;
         }
     }
+#ifdef VG_EIG_RT
+    __syncthreads();
+    if (cblock == 0) RT(5);
+#endif
 }
 
 // =====================================================================================================================
