@@ -72,7 +72,7 @@ def test_cholesky_inverse(engine, m, kind, ell):
     L, Li = L.cpu().numpy(), Li.cpu().numpy()
     Kj = K + jit * np.eye(m)
     # m > 128: blocked path, panels solved with the explicit inverse of the (ill-conditioned) diagonal blocks
-    assert rel(L @ L.T, Kj) < (1e-13 if m <= 128 else 2e-12)
+    assert rel(L @ L.T, Kj) < (3e-13 if m <= 128 else 2e-12)
     assert np.abs(np.triu(L, 1)).max() == 0 and np.abs(np.triu(Li, 1)).max() == 0
     # L Li = I to conditioning
     assert np.abs(L @ Li - np.eye(m)).max() < 1e-9 * max(1.0, np.linalg.cond(Lr) * 1e-4)

@@ -404,22 +404,45 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
 #pragma unroll
             for (int c = 0; c < 4; ++c) { a[c] = Db[i * 17 + 4 * q + c]; x[c] = (i == 4 * q + c) ? 1.0 : 0.0; }
             bool good = true;
+            // TWO pivot columns per LDS round trip: columns k and k+1 (and rows k, k+1 of the running inverse) are published
+            // together; every lane then forms both multipliers itself -- the second pivot is the 2 x 2 Schur complement
+            // p2 = a(k+1,k+1) - a(k+1,k)^2 / p1 -- and applies the rank-2 update.  Halves the round trips of the chain.
 #pragma unroll
-            for (int k = 0; k < VG_CB; ++k) {
-                if (q == (k >> 2)) colbuf[k * 16 + i] = a[k & 3];
+            for (int k = 0; k < VG_CB; k += 2) {
+                if (q == (k >> 2)) { colbuf[k * 16 + i] = a[k & 3]; colbuf[(k + 1) * 16 + i] = a[(k + 1) & 3]; }
                 if (i == k) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xrow[(k & 1) * 16 + 4 * q + c] = x[c];
+                    for (int c = 0; c < 4; ++c) xrow[4 * q + c] = x[c];
+                }
+                if (i == k + 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xrow[16 + 4 * q + c] = x[c];
                 }
                 VG_WAVE_SYNC();
-                const double piv = colbuf[k * 16 + k], li = colbuf[k * 16 + i];
-                double lj[4], xr[4];
+                const double p1 = colbuf[k * 16 + k], m21 = colbuf[k * 16 + k + 1], d2 = colbuf[(k + 1) * 16 + k + 1];
+                const double li1 = colbuf[k * 16 + i], li2 = colbuf[(k + 1) * 16 + i];
+                double lj1[4], lj2[4], xa[4], xb[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { lj[c] = colbuf[k * 16 + 4 * q + c]; xr[c] = xrow[(k & 1) * 16 + 4 * q + c]; }
-                if (!(piv > 0.0) || !(piv < 1.0e300)) { good = false; break; }     // wave-uniform
-                const double lr = (i > k) ? li * vg_crcp(piv) : 0.0;
+                for (int c = 0; c < 4; ++c) {
+                    lj1[c] = colbuf[k * 16 + 4 * q + c]; lj2[c] = colbuf[(k + 1) * 16 + 4 * q + c];
+                    xa[c] = xrow[4 * q + c]; xb[c] = xrow[16 + 4 * q + c];
+                }
+                if (!(p1 > 0.0) || !(p1 < 1.0e300)) { good = false; break; }       // wave-uniform
+                const double g = m21 * vg_crcp(p1);
+                const double p2 = d2 - g * m21;
+                if (!(p2 > 0.0) || !(p2 < 1.0e300)) { good = false; break; }
+                const double l1 = (i > k) ? li1 * vg_crcp(p1) : 0.0;
+                const double c2 = li2 - l1 * m21;                                  // column k+1 after step k (unscaled)
+                const double l2 = (i > k + 1) ? c2 * vg_crcp(p2) : 0.0;
+                VG_WAVE_SYNC();                                                    // everybody has read column k+1 ...
+                if (q == 0 && i > k) colbuf[(k + 1) * 16 + i] = c2;               // ... before it is replaced by its final value
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { a[c] -= lr * lj[c]; x[c] -= lr * xr[c]; }
+                for (int c = 0; c < 4; ++c) {
+                    const double r2 = lj2[c] - g * lj1[c];                         // row k+1 after step k
+                    const double y2 = xb[c] - g * xa[c];
+                    a[c] -= l1 * lj1[c] + l2 * r2;
+                    x[c] -= l1 * xa[c] + l2 * y2;
+                }
             }
             if (good) {
                 if (lane < 16) sdv[lane] = vg_crsq(colbuf[lane * 16 + lane]);      // 1 / L[k][k]
