@@ -20,7 +20,7 @@ fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 calib, _ = per_kernel(sys.argv[3], "FETCH_SIZE")
 cal_bytes = float(os.environ.get("CALIB_BYTES", 0))
-k = "vg_gemm_gram_project_kernel"
+k = "vg_gemm_gram_project_wide_kernel" if "vg_gemm_gram_project_wide_kernel" in fetch else "vg_gemm_gram_project_kernel"
 ck = "vg_sumsq_kernel"
 factor = cal_bytes / (calib[ck] * 1024.0)
 out = {
