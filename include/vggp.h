@@ -56,6 +56,12 @@ extern "C" {
                                      kronecker_structure.py:702-790 == gridded_kronecker_structure.py:1286-1374 */
 #define VGGP_BASIS_ONE    2       /* trivial factor K=[1], A=1: turns the engine into the 1-D model,
                                      univariate_structure.py:234-263, :693-717 */
+#define VGGP_BASIS_VFF    3       /* variational Fourier features (Matern-1/2 only): Matern12VFFGP,
+                                     kronecker_structure.py:346-515.  grid = [a, b, omega_0 .. omega_M], m = 2M + 1.
+                                     Kuu_d = K0(ell) / s_d, Kuf_d = features(x) (no s_d). */
+#define VGGP_BASIS_B1     4       /* B1-spline (hat function) features (Matern-1/2 only): Matern12B1SplineASVGP,
+                                     kronecker_structure.py:524-660.  grid = knot mesh (m knots).
+                                     Kuu_d = (A ell + B / ell + BC) / (2 s_d), Kuf_d = hats(x). */
 
 /* The reference keeps the B0 mesh and delta as float32 attributes (torch.linspace default
  * dtype; Module.to(float64) does not touch them), so `(k - 1) * delta` in _Kuu_along_dim

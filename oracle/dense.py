@@ -136,6 +136,82 @@ def b0_Kuf_along_dim(mesh: torch.Tensor, ell, s, x: torch.Tensor) -> torch.Tenso
 # ----------------------------------------------------------------------------
 # linear-algebra definitions of the linear_operator / gpytorch calls
 # ----------------------------------------------------------------------------
+# ----------------------------------------------------------------------------
+# Variational Fourier features (Matern-1/2) -- Matern12VFFGP, kronecker_structure.py:346-515, basis/fourier.py
+# ----------------------------------------------------------------------------
+def vff_omegas(M: int, a: float, b: float) -> torch.Tensor:
+    """fourier.py:13 -- float32 in the reference (python float * int64 arange / python float)."""
+    return (2 * torch.pi) * torch.arange(M + 1) / (b - a)
+
+
+def vff_Kuu_along_dim(a: float, b: float, omegas: torch.Tensor, ell, s) -> torch.Tensor:
+    """kronecker_structure.py:376-462: Kuu_d = diag(alpha) + beta beta^T with the Matern-1/2 spectral density
+    S(w) = 2 s lam / (lam^2 + w^2), lam = 1/ell.  NB it scales with 1/s, and Kuf_d carries no s at all.
+    The reference evaluates S in float32 (float32 omegas against a 0-dim float64 lam) and casts at the end; here the
+    float32-rounded omegas are used in float64 arithmetic."""
+    om = omegas.to(DT)
+    lam = 1.0 / ell.reshape(())
+    S_inv = (lam ** 2 + om ** 2) / (2 * s * lam)
+    alpha = ((b - a) / 2) * torch.cat([2 * S_inv[0][None], S_inv[1:], S_inv[1:]])
+    beta = torch.cat((torch.ones(len(om), dtype=DT) / torch.sqrt(s), torch.zeros(len(om) - 1, dtype=DT)))
+    return torch.diag(alpha) + beta[:, None] * beta[None, :]
+
+
+def vff_Kuf_along_dim(a: float, b: float, omegas: torch.Tensor, ell, x: torch.Tensor) -> torch.Tensor:
+    """kronecker_structure.py:464-480 + fourier.py:14-88: inside [a, b): cos(w (x-a)) then sin(w[1:] (x-a)); outside:
+    exp(-lam r) on the cosine rows (r = distance to the nearer boundary), 0 on the sine rows.  (2M+1) x n."""
+    om = omegas.to(DT)
+    lam = 1.0 / ell.reshape(())
+    inside = torch.logical_and(x >= a, x < b)
+    xa = x - a
+    cosr = torch.cos(om[:, None] * xa[None, :])
+    sinr = torch.sin(om[1:, None] * xa[None, :])
+    r = torch.minimum(torch.abs(x - a), torch.abs(x - b))
+    out_real = torch.exp(-lam * r)[None, :] * torch.ones(len(om), 1, dtype=DT)
+    real = torch.where(inside[None, :], cosr, out_real)
+    imag = torch.where(inside[None, :], sinr, torch.zeros_like(sinr))
+    return torch.cat([real, imag], dim=0)
+
+
+# ----------------------------------------------------------------------------
+# B1-spline inducing features (Matern-1/2) -- Matern12B1SplineASVGP, kronecker_structure.py:524-660, basis/bspline.py
+# ----------------------------------------------------------------------------
+def b1_Kuu_along_dim(mesh: torch.Tensor, ell, s) -> torch.Tensor:
+    """kronecker_structure.py:560-614, literally: (A * ell + B / ell + BC) / (2 s) with A the L2 Gram matrix of the hat
+    functions (tridiagonal 2d/3, d/6; d/3 at the two ends), B their gradient Gram matrix (2/d, -1/d; 1/d at the ends) and
+    BC = diag(1, 0, ..., 0, 1).  (The reference builds the matrices in float32; float64 here.)"""
+    m = mesh.shape[0]
+    d = (mesh[1] - mesh[0]).to(DT)
+    i = torch.arange(m)
+    off = (torch.abs(i[:, None] - i[None, :]) == 1).to(DT)
+    eye = torch.eye(m, dtype=DT)
+    ends = torch.zeros(m, dtype=DT)
+    ends[0] = ends[-1] = 1.0
+    A = (2 / 3) * d * eye + (1 / 6) * d * off - torch.diag(ends) * (d / 3)
+    B = (2 / d) * eye - (1 / d) * off - torch.diag(ends) / d
+    BC = torch.diag(ends)
+    ell0 = ell.reshape(())
+    return (A * ell0 + B / ell0 + BC) / (2 * s)
+
+
+def b1_Kuf_along_dim(mesh: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """bspline.py:24-112: left half hat on [v0, v1), interior hats (rising on [v_k-1, v_k], falling on (v_k, v_k+1]),
+    right half hat on [v_K-2, v_K-1]; no hyper-parameter enters.  K x n."""
+    v = mesh.to(DT)
+    K = v.shape[0]
+    rows = []
+    B1 = torch.logical_and(x >= v[0], x < v[1]).to(DT)
+    rows.append(((v[1] - x) / (v[1] - v[0])) * B1)
+    for mm in range(K - 2):
+        vm, vm1, vm2 = v[mm], v[mm + 1], v[mm + 2]
+        r0 = torch.logical_and(x >= vm, x <= vm1).to(DT)
+        r1 = torch.logical_and(x > vm1, x <= vm2).to(DT)
+        rows.append(((x - vm) / (vm1 - vm)) * r0 + ((vm2 - x) / (vm2 - vm1)) * r1)
+    r0 = torch.logical_and(x >= v[-2], x <= v[-1]).to(DT)
+    rows.append(((x - v[-2]) / (v[-1] - v[-2])) * r0)
+    return torch.vstack(rows)
+
+
 def psd_safe_cholesky(A: torch.Tensor) -> Tuple[torch.Tensor, float]:
     """linear_operator.utils.cholesky.psd_safe_cholesky, float64 schedule."""
     for jit in JITTERS:
@@ -184,6 +260,8 @@ class DenseKron:
                    grid_1, grid_2 are the knot meshes (nknots each).
     basis="points" Matern12SVGP-shaped pairwise factors (kind in KINDS): grid_1,
                    grid_2 are the per-dimension inducing coordinates Z[:, d].
+    basis="vff"    Matern12VFFGP (kronecker_structure.py:346-515): grid_d = (a_d, b_d, nfrequencies).
+    basis="b1"     Matern12B1SplineASVGP (:524-660): grid_d = knot mesh (nknots).
     raw: 5 raw parameters [ell1, ell2, s1, s2, noise] (gpytorch init = zeros).
     mask: optional bool (N,) -- observed points; masked-out rows of X, y are dropped
           (the reference simply never sees them).
@@ -198,12 +276,17 @@ class DenseKron:
         self.train_inputs = (X,)
         self.train_targets = y
         self.basis, self.kind = basis, kind
-        if basis == "b0" and kind != "matern12":
-            raise ValueError("the B0 closed forms exist for Matern-1/2 only")
-        # b0: keep the mesh dtype as given (float32 in the reference, see b0_Kuu_along_dim)
-        gdt = None if basis == "b0" else DT
-        self.grid_1 = torch.as_tensor(grid_1, dtype=gdt)
-        self.grid_2 = torch.as_tensor(grid_2, dtype=gdt)
+        if basis in ("b0", "vff", "b1") and kind != "matern12":
+            raise ValueError("the B0 / VFF / B1 closed forms exist for Matern-1/2 only")
+        if basis == "vff":
+            # grid_d = (a, b, M): domain limits and number of frequencies; omegas as the reference builds them (float32)
+            self.grid_1 = (float(grid_1[0]), float(grid_1[1]), vff_omegas(int(grid_1[2]), float(grid_1[0]), float(grid_1[1])))
+            self.grid_2 = (float(grid_2[0]), float(grid_2[1]), vff_omegas(int(grid_2[2]), float(grid_2[0]), float(grid_2[1])))
+        else:
+            # b0 / b1: keep the mesh dtype as given (float32 in the reference, see b0_Kuu_along_dim)
+            gdt = None if basis in ("b0", "b1") else DT
+            self.grid_1 = torch.as_tensor(grid_1, dtype=gdt)
+            self.grid_2 = torch.as_tensor(grid_2, dtype=gdt)
         self.raw = (torch.zeros(5, dtype=DT) if raw is None else torch.as_tensor(raw, dtype=DT)).clone()
         self.raw.requires_grad_(True)
         self._jit = None
@@ -221,6 +304,11 @@ class DenseKron:
         g = self.grid_1 if d == 0 else self.grid_2
         if self.basis == "b0":
             return b0_Kuu_along_dim(g.shape[0] - 1, g[1] - g[0], ell, s)
+        if self.basis == "vff":
+            a, b, om = g
+            return vff_Kuu_along_dim(a, b, om, ell, s)
+        if self.basis == "b1":
+            return b1_Kuu_along_dim(g, ell, s)
         return pairwise(self.kind, g, g, ell, s)
 
     def _Kuf_d(self, d: int, x: torch.Tensor) -> torch.Tensor:
@@ -229,11 +317,21 @@ class DenseKron:
         g = self.grid_1 if d == 0 else self.grid_2
         if self.basis == "b0":
             return b0_Kuf_along_dim(g, ell, s, x)
+        if self.basis == "vff":
+            a, b, om = g
+            return vff_Kuf_along_dim(a, b, om, ell, x)
+        if self.basis == "b1":
+            return b1_Kuf_along_dim(g, x)
         return pairwise(self.kind, g, x, ell, s)
 
     def jitters(self) -> Tuple[float, float]:
         th = self.theta()
-        return tuple(factor_jitter(self._Kuu_d(d) / th[2 + d]) for d in (0, 1))
+        return tuple(factor_jitter(self._unit(self._Kuu_d(d), th[2 + d])) for d in (0, 1))
+
+    def _unit(self, K: torch.Tensor, s) -> torch.Tensor:
+        """The outputscale-free factor the jitter schedule is applied to: K / s, or K * s for the inter-domain bases whose
+        Kuu scales with 1/s (vff, b1)."""
+        return K * s if self.basis in ("vff", "b1") else K / s
 
     def _Kuu(self) -> torch.Tensor:
         """:792-806 -- torch.kron(Kuu_1, Kuu_2) (jittered factors, see header)."""
@@ -241,8 +339,9 @@ class DenseKron:
         th = self.theta()
         for d in (0, 1):
             K = self._Kuu_d(d)
-            jit = factor_jitter(K / th[2 + d])
-            Ks.append(K + (th[2 + d] * jit) * torch.eye(K.shape[0], dtype=DT))
+            jit = factor_jitter(self._unit(K, th[2 + d]))
+            scale = 1.0 / th[2 + d] if self.basis in ("vff", "b1") else th[2 + d]
+            Ks.append(K + (scale * jit) * torch.eye(K.shape[0], dtype=DT))
         return torch.kron(Ks[0], Ks[1])
 
     def _Kuf(self, x: torch.Tensor) -> torch.Tensor:

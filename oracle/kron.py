@@ -111,9 +111,10 @@ def b0_A(mesh: np.ndarray, x: np.ndarray, ell: float):
 @dataclass
 class Factor:
     """One dimension's inducing-feature description."""
-    basis: str                  # "b0" | "points" | "one" (trivial factor for 1-D models)
+    basis: str                  # "b0" | "points" | "vff" | "b1" | "one" (trivial factor for 1-D models)
     kind: str                   # matern12 | matern32 | matern52 | rbf
-    grid: np.ndarray            # mesh (m+1 knots) for b0, inducing coords (m) for points
+    grid: np.ndarray            # mesh (m+1 knots) for b0, inducing coords (m) for points, knots (m) for b1,
+                                # [a, b, omega_0 .. omega_M] for vff (m = 2M + 1)
     x: np.ndarray               # the n_d unique observation coordinates along this dim
     f32_kdelta: bool = False    # reproduce the reference's float32 (k*delta) rounding (float32 mesh)
 
@@ -121,7 +122,16 @@ class Factor:
     def m(self) -> int:
         if self.basis == "one":
             return 1
+        if self.basis == "vff":
+            return 2 * (len(self.grid) - 3) + 1
         return len(self.grid) - 1 if self.basis == "b0" else len(self.grid)
+
+    @property
+    def inverse(self) -> bool:
+        """Inter-domain bases whose Kuu_d scales with 1/s_d and whose Kuf_d carries no s_d (vff, b1): B = L^{-1} Kuf is
+        the same sqrt(s) L0^{-1} A0 as for the kernel-evaluated bases, so ELBO, gradient and posterior are unchanged;
+        only u-space quantities (q(v)) see L = L0 / sqrt(s) instead of sqrt(s) L0."""
+        return self.basis in ("vff", "b1")
 
     def build(self, ell: float, x: Optional[np.ndarray] = None):
         """-> (K0, dK0, A0, dA0) at unit outputscale."""
@@ -133,10 +143,65 @@ class Factor:
         if self.basis == "b0":
             K, dK = (b0_K_f32 if self.f32_kdelta else b0_K)(len(g) - 1, float(g[1] - g[0]), ell)
             A, dA = b0_A(g, x, ell)
+        elif self.basis == "vff":
+            K, dK = vff_K(g[0], g[1], g[2:], ell)
+            A, dA = vff_A(g[0], g[1], g[2:], x, ell)
+        elif self.basis == "b1":
+            K, dK = b1_K(g, ell)
+            A, dA = b1_A(g, x)
         else:
             K, dK = points_factor(self.kind, g, g, ell)
             A, dA = points_factor(self.kind, g, x, ell)
         return K, dK, A, dA
+
+
+def vff_K(a: float, b: float, om: np.ndarray, ell: float):
+    """Unit-scale VFF Kuu factor (K_d = K0 / s) and dK0/dell: diag(alpha0) + beta0 beta0^T,
+    alpha0 = (b-a)/4 * c * (1/ell + w^2 ell), c = 2 for w = 0 (kronecker_structure.py:400-462)."""
+    M = len(om) - 1
+    w = np.concatenate([om, om[1:]])
+    c = np.ones(2 * M + 1)
+    c[0] = 2.0
+    alpha = (b - a) / 4.0 * c * (1.0 / ell + w * w * ell)
+    dalpha = (b - a) / 4.0 * c * (-1.0 / (ell * ell) + w * w)
+    beta = np.concatenate([np.ones(M + 1), np.zeros(M)])
+    return np.diag(alpha) + np.outer(beta, beta), np.diag(dalpha)
+
+
+def vff_A(a: float, b: float, om: np.ndarray, x: np.ndarray, ell: float):
+    """VFF Kuf factor (no outputscale) and its ell-derivative (non-zero only outside [a, b))."""
+    x = np.asarray(x, float)
+    inside = (x >= a) & (x < b)
+    xa = x - a
+    r = np.minimum(np.abs(x - a), np.abs(x - b))
+    e = np.exp(-r / ell)
+    real = np.where(inside[None, :], np.cos(om[:, None] * xa[None, :]), e[None, :] * np.ones((len(om), 1)))
+    imag = np.where(inside[None, :], np.sin(om[1:, None] * xa[None, :]), 0.0)
+    dreal = np.where(inside[None, :], 0.0, (r / (ell * ell) * e)[None, :] * np.ones((len(om), 1)))
+    return np.vstack([real, imag]), np.vstack([dreal, np.zeros_like(imag)])
+
+
+def b1_K(mesh: np.ndarray, ell: float):
+    """Unit-scale B1-spline Kuu factor (K_d = K0 / s): (A ell + B / ell + BC) / 2 (kronecker_structure.py:560-614)."""
+    m = len(mesh)
+    d = float(mesh[1] - mesh[0])
+    off = (np.abs(np.arange(m)[:, None] - np.arange(m)[None, :]) == 1).astype(float)
+    ends = np.zeros(m)
+    ends[0] = ends[-1] = 1.0
+    A = (2 / 3) * d * np.eye(m) + (1 / 6) * d * off - np.diag(ends) * (d / 3)
+    B = (2 / d) * np.eye(m) - off / d - np.diag(ends) / d
+    return (A * ell + B / ell + np.diag(ends)) / 2.0, (A - B / (ell * ell)) / 2.0
+
+
+def b1_A(mesh: np.ndarray, x: np.ndarray):
+    """Hat functions at x (bspline.py:24-112); no hyper-parameter."""
+    x = np.asarray(x, float)
+    v = np.asarray(mesh, float)
+    d = v[1] - v[0]
+    A = np.maximum(0.0, 1.0 - np.abs(x[None, :] - v[:, None]) / d)
+    A[:, (x < v[0]) | (x > v[-1])] = 0.0
+    # interval conventions of the reference: the left half hat excludes x = v1 (it is 0 there anyway), nothing else differs
+    return A, np.zeros_like(A)
 
 
 def chol_jitter(K0: np.ndarray) -> Tuple[np.ndarray, float]:
@@ -169,13 +234,17 @@ class DimState:
 def dim_prepare(f: Factor, ell: float, s: float, cols: Optional[slice] = None) -> DimState:
     K0, dK0, A0, dA0 = f.build(ell)
     L0, jit = chol_jitter(K0)
-    L = math.sqrt(s) * L0
-    A, dA = s * A0, s * dA0
+    if f.inverse:                    # K_d = K0 / s, Kuf_d = A0: the same B, V, Mk, but L = L0 / sqrt(s)
+        L = L0 / math.sqrt(s)
+        A, dA, dK = A0, dA0, dK0 / s
+    else:
+        L = math.sqrt(s) * L0
+        A, dA, dK = s * A0, s * dA0, s * dK0
     if cols is not None:
         A, dA = A[:, cols], dA[:, cols]
     B = sla.solve_triangular(L, A, lower=True)
     V = sla.solve_triangular(L, dA, lower=True)
-    X = sla.solve_triangular(L, s * dK0, lower=True)
+    X = sla.solve_triangular(L, dK, lower=True)
     Mk = sla.solve_triangular(L, X.T, lower=True).T
     return DimState(L=L, jit=jit, B=B, V=V, Mk=Mk)
 
@@ -311,7 +380,7 @@ def posterior(st: StepState, f1: Factor, f2: Factor, x_star: np.ndarray):
     Ts = []
     for f, d, ell, s, col in ((f1, st.d1, ell1, s1, 0), (f2, st.d2, ell2, s2, 1)):
         _, _, A0, _ = f.build(ell, x=np.asarray(x_star[:, col], float))
-        Ts.append(d.Q.T @ sla.solve_triangular(d.L, s * A0, lower=True))
+        Ts.append(d.Q.T @ sla.solve_triangular(d.L, A0 if f.inverse else s * A0, lower=True))
     T1, T2 = Ts
     mean = np.einsum("ip,ij,jp->p", T1, st.beta / v, T2)
     var = s1 * s2 + np.einsum("ip,ij,jp->p", T1 * T1, 1.0 / st.D - 1.0, T2 * T2)
@@ -425,13 +494,16 @@ def elbo_step_masked(Y: np.ndarray, W: np.ndarray, f1: Factor, f2: Factor, theta
     return st
 
 
-def q_v_masked(st: MaskedState):
-    """q(v) mean and covariance diagonal, (m1, m2): mu = Kuu Sigma^{-1} c / sigma^2, S = Kuu Sigma^{-1} Kuu."""
+def q_v_masked(st: MaskedState, f1: Optional[Factor] = None, f2: Optional[Factor] = None):
+    """q(v) mean and covariance diagonal, (m1, m2): mu = Kuu Sigma^{-1} c / sigma^2, S = Kuu Sigma^{-1} Kuu.
+    f1, f2 only matter for the inter-domain bases (Kuu_d = K0 / s_d): L_d = s_d^(e_d/2) L0_d with e_d = -1 there."""
     _, _, s1, s2, v = st.theta
     L1, L2 = st.d1.L, st.d2.L                                  # unit-outputscale Cholesky factors
-    mean = (s1 * s2 / v) * (L1 @ st.A0 @ L2.T)
+    e1 = -1 if (f1 is not None and f1.inverse) else 1
+    e2 = -1 if (f2 is not None and f2.inverse) else 1
+    mean = (s1 ** ((1 + e1) / 2) * s2 ** ((1 + e2) / 2) / v) * (L1 @ st.A0 @ L2.T)
     Lk = np.kron(L1, L2)
-    var = s1 * s2 * np.einsum("ab,bc,ac->a", Lk, st.Sinv, Lk)
+    var = (s1 ** e1) * (s2 ** e2) * np.einsum("ab,bc,ac->a", Lk, st.Sinv, Lk)
     return mean, var.reshape(mean.shape)
 
 

@@ -57,6 +57,38 @@ def make_case(name, spec):
     print(name, float(elbo))
 
 
+NEW_BASIS_CASES = {
+    # the reference's VFF and B1-spline models (only the per-dimension factors differ)
+    "vff_m12_24x20": (24, 20, "vff", (-0.1, 1.1, 5), [0.25, 0.2, 1.0, 1.2, 0.01]),
+    "b1_m12_24x20": (24, 20, "b1", 8, [0.25, 0.2, 1.0, 1.2, 0.01]),
+}
+
+
+def make_new_basis_case(name, spec):
+    n1, n2, basis, gs, theta = spec
+    X, y, x1, x2 = D.gen_grid(n1, n2, seed=len(name))
+    raw = D.raw_from_constrained(theta)
+    if basis == "vff":
+        a, b, M = gs
+        dg = (a, b, M)
+        kgrid = np.concatenate([[a, b], D.vff_omegas(M, a, b).double().numpy()])
+    else:
+        mesh = torch.tensor(np.linspace(0, 1, gs))      # float64 mesh: the reference's float32 delta (1e-8 relative) is not reproduced
+        dg = mesh
+        kgrid = mesh.double().numpy()
+    dm = D.DenseKron(X, y, basis, "matern12", dg, dg, raw=raw)
+    elbo, graw = dm.elbo_and_grad()
+    qv = dm.q_v()
+    xs = np.random.default_rng(11).uniform(0, 1, (25, 2))
+    po = dm.posterior(xs)
+    np.savez(os.path.join(HERE, f"oracle_{name}.npz"),
+             X=X, y=y, x1=x1, x2=x2, grid1=kgrid, grid2=kgrid, mesh_is_f32=np.array(False), basis=np.array(basis),
+             kind=np.array("matern12"), raw=raw.numpy(), theta=dm.theta().detach().numpy(), jitter=np.array(dm.jitters()),
+             elbo=elbo.numpy(), grad_raw=graw.numpy(), qv_mean=qv.mean.detach().numpy(), qv_var=qv.variance.detach().numpy(),
+             xs=xs, post_mean=po.mean.detach().numpy(), post_var=po.variance.detach().numpy())
+    print(name, float(elbo))
+
+
 MASK_CASES = {
     # BASELINE.json configs[4]: missing observations under a mask (the reference receives only the observed subset)
     "mask30_b0_m12_32x32": (32, 32, "b0", "matern12", ("lin", 0, 1, 9), ("lin", 0, 1, 9), [0.25, 0.2, 1.0, 1.2, 0.01], "f64", 0.3),
@@ -125,5 +157,7 @@ if __name__ == "__main__":
         make_case(k, v)
     for k, v in MASK_CASES.items():
         make_mask_case(k, v)
+    for k, v in NEW_BASIS_CASES.items():
+        make_new_basis_case(k, v)
     make_1d()
     make_ref_pins()

@@ -256,3 +256,58 @@ def test_failed_step_resets_the_warm_start(engine):
     for _ in range(3):
         elbo, grad, info = engine.elbo_step(Y, yy, theta)
         assert abs(elbo - ref.elbo) <= 1e-9 * abs(ref.elbo) and rel(grad, ref.grad) < 1e-7
+
+
+def _new_basis_case(basis):
+    n1, n2 = 40, 34
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    if basis == "vff":
+        a, b, M = -0.1, 1.1, 6                        # domain strictly larger than the data (as VFF requires)
+        om = D.vff_omegas(M, a, b).double().numpy()   # the reference's float32 omegas
+        g = np.concatenate([[a, b], om])
+        dgrid = (a, b, M)
+    else:
+        g = np.linspace(0, 1, 9)
+        dgrid = torch.tensor(g)
+    return n1, n2, X, y, x1, x2, g, dgrid
+
+
+@pytest.mark.parametrize("basis", ["vff", "b1"])
+def test_interdomain_bases_vs_oracles(engine, basis):
+    """Matern12VFFGP (kronecker_structure.py:346-515) and Matern12B1SplineASVGP (:524-660) only swap the
+    per-dimension factors (Kuu_d scales with 1/s_d, Kuf_d carries no s_d): ELBO, gradient, q(v) and posterior against the
+    structured oracle and the literal dense restatement."""
+    n1, n2, X, y, x1, x2, g, dgrid = _new_basis_case(basis)
+    theta = [0.3, 0.25, 0.9, 1.2, 0.02]
+    f1, f2 = Kr.Factor(basis, "matern12", g, x1), Kr.Factor(basis, "matern12", g, x2)
+    st = Kr.elbo_step(y.reshape(n2, n1), f1, f2, theta)
+    dm = D.DenseKron(X, y, basis, "matern12", dgrid, dgrid, raw=D.raw_from_constrained(theta))
+    ed, gd = dm.elbo_and_grad()
+    engine.plan("matern12", basis, g, x1, "matern12", basis, g, x2)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    elbo, grad, info = engine.elbo_step(Y, engine.sumsq(Y), theta)
+    assert info["jitter"] == (st.d1.jit, st.d2.jit)
+    assert abs(elbo - st.elbo) <= RTOL * abs(st.elbo) and abs(elbo - ed.item()) <= 1e-6 * abs(ed.item())
+    assert rel(grad, st.grad) < RTOL
+    assert rel(Kr.grad_raw(grad, dm.raw.detach().numpy()), gd.numpy()) < 1e-6
+    mean, var = engine.qv()
+    rm, rv = Kr.q_v(st)
+    assert rel(mean.cpu().numpy(), rm) < RTOL and rel(var.cpu().numpy(), rv) < RTOL
+    qd = dm.q_v()
+    assert rel(mean.cpu().numpy().reshape(-1), qd.mean.detach().numpy()) < 1e-6
+    cov = engine.qv_cov().cpu().numpy()
+    assert rel(cov, Kr.q_v_cov(st)) < 1e-6
+    xs = np.random.default_rng(2).uniform(-0.05, 1.05, (64, 2))          # a few points outside the data range
+    pm, pv = engine.posterior(torch.tensor(xs, device=DEV))
+    om_, ov_ = Kr.posterior(st, f1, f2, xs)
+    assert rel(pm.cpu().numpy(), om_) < RTOL and rel(pv.cpu().numpy(), ov_) < 1e-6
+    # masked grid through the same factors
+    Wn = (np.random.default_rng(5).uniform(size=(n2, n1)) > 0.3).astype(np.float64)
+    stm = Kr.elbo_step_masked(y.reshape(n2, n1), Wn, f1, f2, theta)
+    W = torch.tensor(Wn, device=DEV)
+    Ym = Y * W
+    em, gm, im = engine.elbo_step_masked(Ym, W, float(Wn.sum()), engine.sumsq(Ym), theta)
+    assert abs(em - stm.elbo) <= RTOL * abs(stm.elbo) and rel(gm, stm.grad) < RTOL
+    mm, mv = engine.qv_masked()
+    rmm, rmv = Kr.q_v_masked(stm, f1, f2)
+    assert rel(mm.cpu().numpy(), rmm) < RTOL and rel(mv.cpu().numpy(), rmv) < RTOL

@@ -13,7 +13,7 @@ KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 NSTAGE = 14
 FLAG_B0_F32_KDELTA = 1
 FLAG_BLOCK_JACOBI = 2
-BASIS = {"points": 0, "b0": 1, "one": 2}
+BASIS = {"points": 0, "b0": 1, "one": 2, "vff": 3, "b1": 4}
 
 
 class VggpError(RuntimeError):

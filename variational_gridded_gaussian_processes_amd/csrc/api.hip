@@ -117,6 +117,16 @@ static int pick_split(int tiles, int K, int target) {
     return std::max(1, std::min(s, maxs));
 }
 
+// number of doubles in the host/device `grid` array of a dimension
+static long vg_grid_len(int basis, long m) {
+    if (basis == VGGP_BASIS_B0) return m + 1;                 // mesh knots
+    if (basis == VGGP_BASIS_VFF) return 2 + (m - 1) / 2 + 1;  // a, b, omega_0 .. omega_M (m = 2M + 1)
+    return m;                                                 // points / B1 knots / trivial
+}
+// +1: Kuu_d = s_d K0, Kuf_d = s_d A0 (kernel-evaluated bases);  -1: Kuu_d = K0 / s_d, Kuf_d = A0 (inter-domain VFF / B1).
+// B = L^{-1} Kuf is sqrt(s) L0^{-1} A0 either way, so only u-space results (q(v)) need the sign.
+static int vg_uexp(int basis) { return (basis == VGGP_BASIS_VFF || basis == VGGP_BASIS_B1) ? -1 : 1; }
+
 static void layout(vggp_ctx* c, Bump& b) {
     // Allocation ORDER matters: the small kernels of a step are latency chains whose first loads miss everything
     // (the producer ran on another XCD), and each distinct 2 MB region they touch adds an address-translation miss on
@@ -178,7 +188,7 @@ static void layout(vggp_ctx* c, Bump& b) {
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         const long m = d.m;
-        const int glen = d.basis == VGGP_BASIS_B0 ? m + 1 : m;
+        const int glen = (int)vg_grid_len(d.basis, m);
         d.grid = b.take<double>(glen);
         d.K0 = b.take<double>(m * m);
         d.dK0 = b.take<double>(m * m);
@@ -216,7 +226,11 @@ static void layout(vggp_ctx* c, Bump& b) {
 
 static int check_dim(int kind, int basis, long n, long m, const char* which) {
     VG_REQUIRE(kind >= 0 && kind <= 3, "vggp_plan: bad kind for %s", which);
-    VG_REQUIRE(basis >= 0 && basis <= 2, "vggp_plan: bad basis for %s", which);
+    VG_REQUIRE(basis >= 0 && basis <= 4, "vggp_plan: bad basis for %s", which);
+    VG_REQUIRE(!((basis == VGGP_BASIS_VFF || basis == VGGP_BASIS_B1) && kind != VGGP_KIND_MATERN12),
+               "vggp_plan: the VFF and B1 features exist for Matern-1/2 only (%s)", which);
+    VG_REQUIRE(!(basis == VGGP_BASIS_VFF && (m < 3 || (m & 1) == 0)), "vggp_plan: VFF needs m = 2M + 1 >= 3 (%s)", which);
+    VG_REQUIRE(!(basis == VGGP_BASIS_B1 && m < 2), "vggp_plan: B1 needs at least 2 knots (%s)", which);
     VG_REQUIRE(!(basis == VGGP_BASIS_B0 && kind != VGGP_KIND_MATERN12),
                "vggp_plan: the B0 basis exists for Matern-1/2 only (%s)", which);
     VG_REQUIRE(n >= 1, "vggp_plan: %s has no observations", which);
@@ -265,7 +279,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
         if (d.basis == VGGP_BASIS_ONE) {
             VG_HIP(hipMemcpy(d.grid, &one, sizeof(double), hipMemcpyHostToDevice));
         } else {
-            const int glen = d.basis == VGGP_BASIS_B0 ? d.m + 1 : d.m;
+            const int glen = (int)vg_grid_len(d.basis, d.m);
             VG_HIP(hipMemcpy(d.grid, hg, sizeof(double) * glen, hipMemcpyHostToDevice));
         }
     }
@@ -659,7 +673,7 @@ extern "C" int vggp_qv(vggp_ctx* c, double* mean, double* var, void* stream) {
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     int rc = build_RQ(c, st);
     if (rc) return rc;
-    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, st));
+    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, st, vg_uexp(d1.basis), vg_uexp(d2.basis)));
     VgGemmBatch g;
     vg_gemm_init(&g);
     vg_gemm_add(&g, d1.RQ, m1, 1, c->wq, m2, 1, c->T3, (int)m2, (int)m1, (int)m2, (int)m1);
@@ -669,7 +683,7 @@ extern "C" int vggp_qv(vggp_ctx* c, double* mean, double* var, void* stream) {
     vg_gemm_add(&g, c->T3, m2, 1, d2.RQ, 1, m2, mean, (int)m2, (int)m1, (int)m2, (int)m2);
     vg_gemm_add(&g, c->T3 + m1 * m2, m2, 1, d2.RQsq, 1, m2, var, (int)m2, (int)m1, (int)m2, (int)m2);
     VG_HIP(vg_gemm_launch(&g, st));
-    VG_HIP(vg_scale_launch(var, m1 * m2, c->theta, 0, st));
+    VG_HIP(vg_scale_launch(var, m1 * m2, c->theta, 0, st, vg_uexp(d1.basis), vg_uexp(d2.basis)));
     return VGGP_OK;
 }
 
@@ -707,7 +721,7 @@ extern "C" int vggp_qv_cov(vggp_ctx* c, double* cov, void* stream) {
     vg_gemm_init(&g);
     vg_gemm_add(&g, Rs, M, 1, Rk, 1, M, cov, (int)M, (int)M, (int)M, (int)M);
     VG_HIP(vg_gemm_launch(&g, st));
-    VG_HIP(vg_scale_launch(cov, M * M, c->theta, 0, st));
+    VG_HIP(vg_scale_launch(cov, M * M, c->theta, 0, st, vg_uexp(c->d[0].basis), vg_uexp(c->d[1].basis)));
     return VGGP_OK;
 }
 
@@ -767,7 +781,9 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
 extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double* x, int64_t n, const double* grid,
                                  int64_t m, double ell, int flags, double* A0, double* dA0, double* K0, double* dK0, void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
-    VG_REQUIRE(kind >= 0 && kind <= 3 && basis >= 0 && basis <= 2, "vggp_factor_build: bad kind/basis");
+    VG_REQUIRE(kind >= 0 && kind <= 3 && basis >= 0 && basis <= 4, "vggp_factor_build: bad kind/basis");
+    VG_REQUIRE(!((basis == VGGP_BASIS_VFF || basis == VGGP_BASIS_B1) && kind != VGGP_KIND_MATERN12),
+               "vggp_factor_build: VFF / B1 are Matern-1/2 only");
     VG_REQUIRE(!(basis == VGGP_BASIS_B0 && kind != VGGP_KIND_MATERN12), "vggp_factor_build: B0 is Matern-1/2 only");
     VG_REQUIRE(n >= 0 && m >= 1 && ell > 0.0, "vggp_factor_build: bad sizes / lengthscale");
     VG_REQUIRE(grid || basis == VGGP_BASIS_ONE, "vggp_factor_build: null grid");

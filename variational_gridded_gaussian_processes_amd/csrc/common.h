@@ -191,9 +191,9 @@ hipError_t vg_clear_launch(const VgClearArgs* a, hipStream_t st);
 // q(v) / posterior helpers
 hipError_t vg_scale_sq_launch(const double* in, double* out_sq, long n, hipStream_t st);
 hipError_t vg_qv_weights_launch(const double* theta, const double* beta, const double* invD, double* w_mean,
-                                long n, hipStream_t st);
+                                long n, hipStream_t st, int e1 = 1, int e2 = 1);
 hipError_t vg_sumsq_launch(const double* y, long n, double* partial, double* out, hipStream_t st);
 hipError_t vg_post_combine_launch(const double* theta, const double* T1, const double* T2, const double* beta,
                                   const double* invD, int m1, int m2, long ns, double* mean, double* var,
                                   hipStream_t st);
-hipError_t vg_scale_launch(double* x, long n, const double* theta, int mode, hipStream_t st);
+hipError_t vg_scale_launch(double* x, long n, const double* theta, int mode, hipStream_t st, int e1 = 1, int e2 = 1);

@@ -131,6 +131,48 @@ __global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs args,
         } else {
             vg_b0_A(J.grid[k], J.grid[k + 1], J.x[p], ell, v, dv);
         }
+    } else if (J.basis == VGGP_BASIS_VFF) {
+        // grid = [a, b, omega_0 .. omega_M], m = 2M + 1: rows 0..M cosine features, M+1..2M sine features
+        const double a = J.grid[0], b = J.grid[1];
+        const int M = (m - 1) >> 1;
+        if (kpart) {
+            // unit-scale Kuu factor: diag(alpha0) + beta0 beta0^T, alpha0 = (b-a)/4 c (1/ell + w^2 ell), c = 2 at w = 0
+            const double w = J.grid[2 + (k <= M ? k : k - M)];
+            const double cc = (b - a) * 0.25 * (k == 0 ? 2.0 : 1.0);
+            v = (k <= M && p <= M) ? 1.0 : 0.0;
+            dv = 0.0;
+            if (k == p) { v += cc * (1.0 / ell + w * w * ell); dv = cc * (-1.0 / (ell * ell) + w * w); }
+        } else {
+            const double x = J.x[p];
+            const bool inside = x >= a && x < b;
+            if (inside) {
+                const double w = J.grid[2 + (k <= M ? k : k - M)];
+                v = k <= M ? cos(w * (x - a)) : sin(w * (x - a));
+                dv = 0.0;
+            } else {
+                const double r = fmin(fabs(x - a), fabs(x - b)), e = exp(-r / ell);
+                v = k <= M ? e : 0.0;
+                dv = k <= M ? r / (ell * ell) * e : 0.0;
+            }
+        }
+    } else if (J.basis == VGGP_BASIS_B1) {
+        // grid = knot mesh v_0 .. v_{m-1}
+        const double d = J.grid[1] - J.grid[0];
+        if (kpart) {
+            // (A ell + B / ell + BC) / 2: A tridiagonal (2d/3, d/6; d/3 at the ends), B (2/d, -1/d; 1/d at the ends), BC = ends
+            const int kd = k > p ? k - p : p - k;
+            const bool end = (k == 0 || k == m - 1);
+            double Aij = 0.0, Bij = 0.0, BCij = 0.0;
+            if (kd == 0) { Aij = end ? d / 3.0 : 2.0 * d / 3.0; Bij = end ? 1.0 / d : 2.0 / d; BCij = end ? 1.0 : 0.0; }
+            else if (kd == 1) { Aij = d / 6.0; Bij = -1.0 / d; }
+            v = 0.5 * (Aij * ell + Bij / ell + BCij);
+            dv = 0.5 * (Aij - Bij / (ell * ell));
+        } else {
+            const double x = J.x[p];
+            const bool in = x >= J.grid[0] && x <= J.grid[m - 1];
+            v = in ? fmax(0.0, 1.0 - fabs(x - J.grid[k]) / d) : 0.0;
+            dv = 0.0;
+        }
     } else {
         const double other = kpart ? J.grid[p] : J.x[p];
         vg_kappa(J.kind, fabs(J.grid[k] - other), ell, v, dv);

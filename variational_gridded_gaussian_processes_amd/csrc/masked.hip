@@ -158,16 +158,17 @@ __global__ void vgm_kron_kernel(const double* L1, const double* L2, int m1, int 
     const long row = idx / M, col = idx - row * M;
     Lk[idx] = L1[(row / m2) * m1 + col / m2] * L2[(row % m2) * m2 + col % m2];
 }
-__global__ void vgm_rowdot_scale_kernel(const double* A, const double* B, long M, const double* theta, double* out) {
+// e_d = +1: Kuu_d = s_d K0;  e_d = -1: Kuu_d = K0 / s_d (inter-domain VFF / B1 features): q(v) = L (...) with L = s^(e/2) L0
+__global__ void vgm_rowdot_scale_kernel(const double* A, const double* B, long M, const double* theta, double* out, int e1, int e2) {
     const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= M) return;
     double s = 0.0;
     for (long b = 0; b < M; ++b) s += A[a * M + b] * B[a * M + b];
-    out[a] = theta[2] * theta[3] * s;
+    out[a] = (e1 > 0 ? theta[2] : 1.0 / theta[2]) * (e2 > 0 ? theta[3] : 1.0 / theta[3]) * s;
 }
-__global__ void vgm_scale_rho_kernel(double* x, long n, const double* theta) {
+__global__ void vgm_scale_rho_kernel(double* x, long n, const double* theta, int e1, int e2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] *= theta[2] * theta[3] / theta[4];
+    if (i < n) x[i] *= (e1 > 0 ? theta[2] : 1.0) * (e2 > 0 ? theta[3] : 1.0) / theta[4];      // s_d^((1 + e_d) / 2) / sigma^2
 }
 
 #define VGM_LAUNCH1D(kern, n, st, ...) \
@@ -417,10 +418,12 @@ extern "C" int vggp_qv_masked(vggp_ctx* c, double* mean, double* var, void* stre
     int rc;
     if ((rc = gemm1(c->d[0].L0, m1, 1, w.a0, m2, 1, w.MkA1, (int)m2, (int)m1, (int)m2, (int)m1, st))) return rc;      // L1 A0
     if ((rc = gemm1(w.MkA1, m2, 1, c->d[1].L0, 1, m2, mean, (int)m2, (int)m1, (int)m2, (int)m2, st))) return rc;     // . L2^T
-    VGM_LAUNCH1D(vgm_scale_rho_kernel, M, st, mean, M, c->theta);
+    const int e1 = (c->d[0].basis == VGGP_BASIS_VFF || c->d[0].basis == VGGP_BASIS_B1) ? -1 : 1;
+    const int e2 = (c->d[1].basis == VGGP_BASIS_VFF || c->d[1].basis == VGGP_BASIS_B1) ? -1 : 1;
+    VGM_LAUNCH1D(vgm_scale_rho_kernel, M, st, mean, M, c->theta, e1, e2);
     VGM_LAUNCH1D(vgm_kron_kernel, M * M, st, c->d[0].L0, c->d[1].L0, (int)m1, (int)m2, w.R);
     if ((rc = gemm1(w.R, M, 1, w.Sinv, M, 1, w.Sg, (int)M, (int)M, (int)M, (int)M, st))) return rc;
-    VGM_LAUNCH1D(vgm_rowdot_scale_kernel, M, st, w.Sg, w.R, M, c->theta, var);
+    VGM_LAUNCH1D(vgm_rowdot_scale_kernel, M, st, w.Sg, w.R, M, c->theta, var, e1, e2);
     VG_HIP(hipGetLastError());
     VG_HIP(hipStreamSynchronize(st));
     return VGGP_OK;

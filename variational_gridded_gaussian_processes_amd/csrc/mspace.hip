@@ -293,31 +293,32 @@ hipError_t vg_scale_sq_launch(const double* in, double* out_sq, long n, hipStrea
 }
 
 // w_mean = beta * sqrt(s1 s2) / v ;   w_var (second half of the buffer) = invD - 1
-__global__ void vg_qv_weights_kernel(const double* theta, const double* beta, const double* invD, double* w, long n) {
+// e_d = +1: Kuu_d = s_d K0 (R_d = sqrt(s_d) L0 Q);  e_d = -1: Kuu_d = K0 / s_d (inter-domain VFF / B1 features)
+__global__ void vg_qv_weights_kernel(const double* theta, const double* beta, const double* invD, double* w, long n, int e1, int e2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const double rs = sqrt(theta[2] * theta[3]);
+        const double rs = sqrt((e1 > 0 ? theta[2] : 1.0 / theta[2]) * (e2 > 0 ? theta[3] : 1.0 / theta[3]));
         w[i] = beta[i] * rs / theta[4];
         w[n + i] = invD[i] - 1.0;
     }
 }
 hipError_t vg_qv_weights_launch(const double* theta, const double* beta, const double* invD, double* w_mean,
-                                long n, hipStream_t st) {
+                                long n, hipStream_t st, int e1, int e2) {
     hipLaunchKernelGGL(vg_qv_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, beta,
-                       invD, w_mean, n);
+                       invD, w_mean, n, e1, e2);
     return hipGetLastError();
 }
 
 // mode 0: x *= s1*s2 ; mode 1: x = s1*s2*(1 + x)
-__global__ void vg_scale_kernel(double* x, long n, const double* theta, int mode) {
+__global__ void vg_scale_kernel(double* x, long n, const double* theta, int mode, int e1, int e2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const double s12 = theta[2] * theta[3];
+        const double s12 = (e1 > 0 ? theta[2] : 1.0 / theta[2]) * (e2 > 0 ? theta[3] : 1.0 / theta[3]);
         x[i] = mode == 0 ? x[i] * s12 : s12 * (1.0 + x[i]);
     }
 }
-hipError_t vg_scale_launch(double* x, long n, const double* theta, int mode, hipStream_t st) {
-    hipLaunchKernelGGL(vg_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, theta, mode);
+hipError_t vg_scale_launch(double* x, long n, const double* theta, int mode, hipStream_t st, int e1, int e2) {
+    hipLaunchKernelGGL(vg_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, theta, mode, e1, e2);
     return hipGetLastError();
 }
 

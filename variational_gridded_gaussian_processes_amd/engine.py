@@ -31,6 +31,17 @@ def _dvec(x) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
 
 
+def _basis_m(basis: str, g: np.ndarray) -> int:
+    """Number of inducing features of a dimension from its grid array."""
+    if basis == "one":
+        return 1
+    if basis == "b0":
+        return len(g) - 1
+    if basis == "vff":
+        return 2 * (len(g) - 3) + 1
+    return len(g)
+
+
 class Engine:
     """Owns a vggp_ctx.  See include/vggp.h for the contract of every call."""
 
@@ -62,13 +73,12 @@ class Engine:
     def plan(self, kind1: str, basis1: str, grid1, x1, kind2: str, basis2: str, grid2, x2,
              n_total: Optional[int] = None, warm_start: bool = False, b0_f32_kdelta: bool = False,
              block_jacobi: bool = False) -> None:
-        """grid_d: mesh (m+1 knots, basis 'b0') or inducing coordinates (m, basis 'points');
-        x_d: the n_d unique (local) observation coordinates along dimension d."""
+        """grid_d: mesh (m+1 knots, basis 'b0'), inducing coordinates (m, 'points'), knot mesh (m, 'b1') or
+        [a, b, omega_0 .. omega_M] (m = 2M + 1, 'vff'); x_d: the n_d unique (local) observation coordinates along d."""
         x1, x2 = _dvec(x1), _dvec(x2)
         g1 = _dvec(grid1) if basis1 != "one" else np.ones(1)
         g2 = _dvec(grid2) if basis2 != "one" else np.ones(1)
-        m1 = 1 if basis1 == "one" else (len(g1) - 1 if basis1 == "b0" else len(g1))
-        m2 = 1 if basis2 == "one" else (len(g2) - 1 if basis2 == "b0" else len(g2))
+        m1, m2 = _basis_m(basis1, g1), _basis_m(basis2, g2)
         d = Desc()
         d.kind1, d.basis1, d.kind2, d.basis2 = KIND[kind1], BASIS[basis1], KIND[kind2], BASIS[basis2]
         d.n1, d.n2, d.m1, d.m2 = len(x1), len(x2), m1, m2
@@ -175,7 +185,7 @@ class Engine:
     def factor_build(self, kind: str, basis: str, x: torch.Tensor, grid: torch.Tensor, ell: float, flags: int = 0):
         """-> A0[m,n], dA0[m,n], K0[m,m], dK0[m,m] at unit outputscale."""
         n = x.shape[0]
-        m = 1 if basis == "one" else (grid.shape[0] - 1 if basis == "b0" else grid.shape[0])
+        m = _basis_m(basis, np.empty(grid.shape[0]))
         o = dict(dtype=torch.float64, device=self.device)
         A, dA, K, dK = torch.empty(m, n, **o), torch.empty(m, n, **o), torch.empty(m, m, **o), torch.empty(m, m, **o)
         check(self.lib.vggp_factor_build(self._h, KIND[kind], BASIS[basis], _ptr(x), n, _ptr(grid), m, float(ell), int(flags),

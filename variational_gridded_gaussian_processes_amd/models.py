@@ -283,12 +283,16 @@ class KroneckerStructure(torch.nn.Module):
         """kronecker_structure.py:702-739 (B0) / :318-319 (points): m_d x m_d, outputscale applied (no jitter)."""
         s = (self.kernel_1 if d == 0 else self.kernel_2).outputscale.detach().to(torch.float64)
         _, K = self._factor(d, torch.zeros(1, dtype=torch.float64))
+        if self._basis()[0] in ("vff", "b1"):          # inter-domain features: Kuu_d = K0 / s_d
+            return (K / s.to(K.device)).cpu()
         return (s.to(K.device) * K).cpu()
 
     def _Kuf_along_dim(self, d: int, x: torch.Tensor) -> torch.Tensor:
         """kronecker_structure.py:741-790 (B0) / :336-337 (points): m_d x len(x)."""
         s = (self.kernel_1 if d == 0 else self.kernel_2).outputscale.detach().to(torch.float64)
         A, _ = self._factor(d, x)
+        if self._basis()[0] in ("vff", "b1"):          # ... and Kuf_d carries no outputscale
+            return A.cpu()
         return (s.to(A.device) * A).cpu()
 
     def _Kuu(self) -> torch.Tensor:
@@ -387,6 +391,45 @@ class Matern12GriddedGP(_B0Gridded):
 
 class Matern12B0SplineGriddedGP(_B0Gridded):
     """kronecker_structure.py:671-849 (identical maths)."""
+
+
+class Matern12VFFGP(KroneckerStructure):
+    """kronecker_structure.py:346-515: variational Fourier features, Matern-1/2.  Kuu_d = diag(alpha) + beta beta^T (:400-462,
+    scales with 1/s_d), Kuf_d = Fourier basis (fourier.py:14-88, no s_d): only the per-dimension factors differ."""
+
+    def __init__(self, X, y, nfrequencies: int, dim1lims: Tuple[float, float], dim2lims: Tuple[float, float], **kw):
+        super().__init__(X, y, **kw)
+        self.nfrequencies = nfrequencies
+        self.dim1lims, self.dim2lims = dim1lims, dim2lims
+        # fourier.py:13, float32 like the reference (python float * int64 arange / python float)
+        self.omegas_1 = (2 * torch.pi) * torch.arange(nfrequencies + 1) / (dim1lims[1] - dim1lims[0])
+        self.omegas_2 = (2 * torch.pi) * torch.arange(nfrequencies + 1) / (dim2lims[1] - dim2lims[0])
+
+    def _basis(self):
+        g1 = np.concatenate([[self.dim1lims[0], self.dim1lims[1]], self.omegas_1.double().numpy()])
+        g2 = np.concatenate([[self.dim2lims[0], self.dim2lims[1]], self.omegas_2.double().numpy()])
+        return "vff", g1, g2
+
+
+class Matern12B1SplineASVGP(KroneckerStructure):
+    """kronecker_structure.py:524-660: B1-spline (hat function) inducing features, Matern-1/2.
+    Kuu_d = (A ell + B / ell + BC) / (2 s_d) (:560-614, tridiagonal), Kuf_d = hats(x) (:616-628)."""
+
+    def __init__(self, X, y, nknots: int, dim1lims: Tuple[float, float], dim2lims: Tuple[float, float], **kw):
+        super().__init__(X, y, **kw)
+        self.nknots = nknots
+        self.dim1lims, self.dim2lims = dim1lims, dim2lims
+        self.mesh_1 = torch.linspace(dim1lims[0], dim1lims[1], nknots)
+        self.mesh_2 = torch.linspace(dim2lims[0], dim2lims[1], nknots)
+        self.delta_1 = self.mesh_1[1] - self.mesh_1[0]
+        self.delta_2 = self.mesh_2[1] - self.mesh_2[0]
+        self.delta = self.delta_1
+
+    def _basis(self):
+        return "b1", self.mesh_1.double().numpy(), self.mesh_2.double().numpy()
+
+    def _f32_mesh(self) -> bool:
+        return False                 # the float32 (k*delta) quirk belongs to the B0 closed forms only
 
 
 class Matern12SVGP(KroneckerStructure):
