@@ -147,6 +147,17 @@ int vggp_qv_masked(vggp_ctx* ctx, double* mean, double* var, void* stream);
 int vggp_posterior_masked(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t n_star, double* mean, double* var,
                           void* stream);
 
+/* Gridded read-out q(v) of B0 cell features v from the posterior over the inducing features u of the last finished step
+ * (q_u -> p(v|u) -> q_v; gridded_kronecker_structure.py:396-438 SVGP, :613-654 VFF, :903-947 ASVGP), Kronecker in the
+ * per-dimension cross-covariances: C_d DEVICE [mv_d][m_d] = Cov(v, u) along dimension d at UNIT outputscale (Kvu_d / s_d
+ * for kernel-evaluated features, Kvu_d itself for VFF / B1 features), kd_d DEVICE [mv_d] = diag(Kvv_d) / s_d.
+ * mean, var DEVICE [mv1][mv2]:  mean = Kvu Kuu^-1 mu_u;  var = diag(Kvv - Kvu Kuu^-1 Kuv + Kvu X Kuv) with
+ * X = S_u^-1 when flags & VGGP_READOUT_LITERAL (what the reference's q_v computes, :431) and X = Kuu^-1 S_u Kuu^-1
+ * (the conditional variance of v under q(u)) otherwise. */
+#define VGGP_READOUT_LITERAL 1
+int vggp_readout(vggp_ctx* ctx, const double* C1, int64_t mv1, const double* C2, int64_t mv2, const double* kd1, const double* kd2,
+                 double* mean, double* var, int flags, void* stream);
+
 /* q(v) of the last finished step: mean and diagonal of the covariance, both DEVICE
  * [m1][m2] (flat index u = i1*m2+i2).  Replaces Matern12GriddedGP.q_v
  * (gridded_kronecker_structure.py:1409-1433 == kronecker_structure.py:825-849). */

@@ -350,6 +350,42 @@ class DenseKron:
         Kuf_2 = self._Kuf_d(1, x[:, 1])
         return (Kuf_1[:, None, :] * Kuf_2[None, :, :]).reshape(-1, x.shape[0])
 
+    # -- gridded read-out q_u -> p(v|u) -> q_v (gridded_kronecker_structure.py:396-438, :613-654) --------------------
+    def _Kvu_d(self, d: int, mesh: torch.Tensor) -> torch.Tensor:
+        """Cov(v, u) along dimension d, v = B0 cell features on `mesh`: :281-338 (points: the B0 closed form at the
+        inducing coordinates), :499-555 (VFF: cell integrals of the Fourier features; no outputscale)."""
+        th = self.theta()
+        ell, s = th[d:d + 1], th[2 + d]
+        g = self.grid_1 if d == 0 else self.grid_2
+        if self.basis == "points" and self.kind == "matern12":
+            return b0_Kuf_along_dim(mesh, ell, s, g)
+        if self.basis == "vff":
+            a, _, om = g
+            om = om.to(DT)
+            me = mesh.to(DT)
+            delta = me[1] - me[0]
+            k0 = torch.ones(me.shape[0] - 1, 1, dtype=DT) * delta
+            kc = (torch.sin(om[1:] * (me[1:] - a)[:, None]) - torch.sin(om[1:] * (me[:-1] - a)[:, None])) / om[1:]
+            ks = -(torch.cos(om[1:] * (me[1:] - a)[:, None]) - torch.cos(om[1:] * (me[:-1] - a)[:, None])) / om[1:]
+            return torch.cat([k0, kc, ks], dim=1)
+        raise NotImplementedError("gridded read-out: points (Matern-1/2) and vff inducing features")
+
+    def q_v_gridded(self, mesh_1: torch.Tensor, mesh_2: torch.Tensor, literal: bool = True) -> MVN:
+        """:417-438 / :634-654: mean = Kvu Kuu^-1 mu_u, cov = Kvv - Kvu Kuu^-1 Kuv + Kvu X Kuv with X = S_u^-1 (literal: what
+        the reference computes) or X = Kuu^-1 S_u Kuu^-1 (the conditional covariance of v under q(u))."""
+        th = self.theta()
+        Kuu = self._Kuu()
+        Kvu = torch.kron(self._Kvu_d(0, mesh_1), self._Kvu_d(1, mesh_2))
+        Kvv = torch.kron(b0_Kuu_along_dim(mesh_1.shape[0] - 1, mesh_1[1] - mesh_1[0], th[0:1], th[2]),
+                         b0_Kuu_along_dim(mesh_2.shape[0] - 1, mesh_2[1] - mesh_2[0], th[1:2], th[3]))
+        qu = self.q_v()                                   # q(u) in these classes' naming: mean Kuu Sigma^-1 Kuf y / s2, cov Kuu Sigma^-1 Kuu
+        Su = qu.covariance_matrix
+        mean = Kvu @ inv_matmul(Kuu, qu.mean)
+        KiKuv = inv_matmul(Kuu, Kvu.T)
+        X = inv_matmul(Su, Kvu.T) if literal else inv_matmul(Kuu, Su @ KiKuv)
+        cov = Kvv - Kvu @ KiKuv + Kvu @ X
+        return MVN(mean, cov)
+
     def _sigma(self) -> torch.Tensor:
         """:134-150."""
         noise = self.theta()[4]

@@ -519,3 +519,43 @@ def posterior_masked(st: MaskedState, f1: Factor, f2: Factor, x_star: np.ndarray
     mean = (s1 * s2 / v) * (T.T @ st.A0.reshape(-1))
     var = s1 * s2 * (1.0 - (T * T).sum(0) + np.einsum("up,uw,wp->p", T, st.Sinv, T))
     return mean, var
+
+
+# ----------------------------------------------------------------------------
+# gridded read-out q_u -> p(v|u) -> q_v of B0 cell features (gridded_kronecker_structure.py:396-438, :613-654), Kronecker
+# in the per-dimension cross-covariances
+# ----------------------------------------------------------------------------
+def cross_b0(f: Factor, mesh: np.ndarray, ell: float):
+    """Unit-outputscale Cov(v, u) along one dimension (mv x m) for B0 cells on `mesh`, and the unit diagonal of Kvv."""
+    mesh = np.asarray(mesh, float)
+    g = np.asarray(f.grid, float)
+    if f.basis == "points":
+        if f.kind != "matern12":
+            raise ValueError("the B0 cross-covariance closed forms are Matern-1/2")
+        C = b0_A(mesh, g, ell)[0]
+    elif f.basis == "vff":
+        a, om = g[0], g[2:]
+        d = mesh[1] - mesh[0]
+        k0 = np.full((len(mesh) - 1, 1), d)
+        kc = (np.sin(om[1:] * (mesh[1:] - a)[:, None]) - np.sin(om[1:] * (mesh[:-1] - a)[:, None])) / om[1:]
+        ks = -(np.cos(om[1:] * (mesh[1:] - a)[:, None]) - np.cos(om[1:] * (mesh[:-1] - a)[:, None])) / om[1:]
+        C = np.hstack([k0, kc, ks])
+    else:
+        raise NotImplementedError(f.basis)
+    kd = np.full(len(mesh) - 1, b0_K(len(mesh) - 1, float(mesh[1] - mesh[0]), ell)[0][0, 0])
+    return C, kd
+
+
+def readout(st: StepState, f1: Factor, f2: Factor, C1, C2, kd1, kd2, literal: bool = True):
+    """mean (mv1, mv2) and variance of q(v): t_d = Q_d^T L_d^{-1} Kuv_d, mean = T1^T (beta / v) T2,
+    var = Kvv_aa Kvv_bb + sum_ij T1[i,a]^2 W_ij T2[j,b]^2 with W = D - 1 (literal reference) or 1/D - 1."""
+    _, _, s1, s2, v = st.theta
+    Ts = []
+    for f, d, s, C in ((f1, st.d1, s1, C1), (f2, st.d2, s2, C2)):
+        Kuv = C.T if f.inverse else s * C.T
+        Ts.append(d.Q.T @ sla.solve_triangular(d.L, Kuv, lower=True))
+    T1, T2 = Ts
+    W = st.D - 1.0 if literal else 1.0 / st.D - 1.0
+    mean = T1.T @ (st.beta / v) @ T2
+    var = s1 * s2 * np.outer(kd1, kd2) + (T1 * T1).T @ W @ (T2 * T2)
+    return mean, var

@@ -311,3 +311,31 @@ def test_interdomain_bases_vs_oracles(engine, basis):
     mm, mv = engine.qv_masked()
     rmm, rmv = Kr.q_v_masked(stm, f1, f2)
     assert rel(mm.cpu().numpy(), rmm) < RTOL and rel(mv.cpu().numpy(), rmv) < RTOL
+
+
+@pytest.mark.parametrize("basis", ["vff", "points"])
+@pytest.mark.parametrize("literal", [True, False], ids=["literal", "conditional"])
+def test_gridded_readout_vs_oracle(engine, basis, literal):
+    """q_u -> p(v|u) -> q_v for B0 cell features (gridded_kronecker_structure.py:396-438, :613-654),
+    Kronecker in the per-dimension cross-covariances, against the structured oracle (== the dense literal formulas to 1e-14,
+    checked on the CPU in tests/test_oracle.py)."""
+    n1, n2 = 40, 34
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    if basis == "vff":
+        a, b, M = -0.1, 1.1, 6
+        g = np.concatenate([[a, b], D.vff_omegas(M, a, b).double().numpy()])
+    else:
+        g = np.linspace(0, 1, 11)
+    theta = [0.3, 0.25, 0.9, 1.2, 0.02]
+    f1, f2 = Kr.Factor(basis, "matern12", g, x1), Kr.Factor(basis, "matern12", g, x2)
+    st = Kr.elbo_step(y.reshape(n2, n1), f1, f2, theta)
+    mesh1, mesh2 = np.linspace(0, 1, 8), np.linspace(0.1, 0.9, 6)
+    C1, kd1 = Kr.cross_b0(f1, mesh1, theta[0])
+    C2, kd2 = Kr.cross_b0(f2, mesh2, theta[1])
+    rm, rv = Kr.readout(st, f1, f2, C1, C2, kd1, kd2, literal=literal)
+    engine.plan("matern12", basis, g, x1, "matern12", basis, g, x2)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    engine.elbo_step(Y, engine.sumsq(Y), theta)
+    mean, var = engine.readout(torch.tensor(C1), torch.tensor(C2), torch.tensor(kd1), torch.tensor(kd2), literal=literal)
+    assert mean.shape == (7, 5)
+    assert rel(mean.cpu().numpy(), rm) < RTOL and rel(var.cpu().numpy(), rv) < 1e-6

@@ -232,3 +232,22 @@ def test_interdomain_models_vs_dense(engine, cls, basis):
     assert rel(model._Kuu().numpy(), torch.kron(dm._Kuu_d(0), dm._Kuu_d(1)).detach().numpy()) < 1e-5
     hist = model.fit(n_iter=4, lr=0.05)
     assert hist[-1] < hist[0]
+
+
+def test_gridded_vff_model_vs_dense(engine):
+    """GriddedMatern12VFFGP (gridded_kronecker_structure.py:470-654): the gridded read-out through the model API against
+    the literal dense formulas."""
+    from variational_gridded_gaussian_processes_amd.models import GriddedMatern12VFFGP
+    n1, n2, nf, ns = 24, 20, 5, 7
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    lims = (-0.1, 1.1)
+    model = GriddedMatern12VFFGP(torch.tensor(X), torch.tensor(y), nf, lims, lims, ns, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    dm = D.DenseKron(X, y, "vff", "matern12", (lims[0], lims[1], nf), (lims[0], lims[1], nf))
+    mesh = torch.linspace(0, 1, ns + 1)
+    qd = dm.q_v_gridded(mesh, mesh, literal=True)
+    qv = model.q_v()
+    assert qv.mean.shape == (ns * ns,)
+    assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5
+    assert rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+    qu, qud = model.q_u(), dm.q_v()
+    assert rel(qu.mean.numpy(), qud.mean.detach().numpy()) < 1e-5

@@ -170,3 +170,28 @@ def test_b0_closed_forms_are_cell_integrals():
     Km, _ = Kr.b0_K(5, mesh[1] - mesh[0], ell - h)
     _, dK = Kr.b0_K(5, mesh[1] - mesh[0], ell)
     assert np.abs((Kp - Km) / (2 * h) - dK).max() < 1e-8
+
+
+@pytest.mark.parametrize("basis", ["vff", "points"])
+@pytest.mark.parametrize("literal", [True, False])
+def test_gridded_readout_structured_equals_dense(basis, literal):
+    """q_u -> p(v|u) -> q_v (gridded_kronecker_structure.py:396-438, :613-654): Kronecker read-out == dense literal formulas."""
+    n1, n2 = 18, 14
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    th = [0.3, 0.25, 0.9, 1.2, 0.02]
+    if basis == "vff":
+        a, b, M = -0.1, 1.1, 4
+        g, dg = np.concatenate([[a, b], D.vff_omegas(M, a, b).double().numpy()]), (a, b, M)
+    else:
+        g = np.linspace(0, 1, 7)
+        dg = torch.tensor(g)
+    mesh = np.linspace(0, 1, 6)
+    dm = D.DenseKron(X, y, basis, "matern12", dg, dg, raw=D.raw_from_constrained(th))
+    f1, f2 = Kr.Factor(basis, "matern12", g, x1), Kr.Factor(basis, "matern12", g, x2)
+    st = Kr.elbo_step(y.reshape(n2, n1), f1, f2, th)
+    C1, kd1 = Kr.cross_b0(f1, mesh, th[0])
+    C2, kd2 = Kr.cross_b0(f2, mesh, th[1])
+    q = dm.q_v_gridded(torch.tensor(mesh), torch.tensor(mesh), literal=literal)
+    m_, v_ = Kr.readout(st, f1, f2, C1, C2, kd1, kd2, literal=literal)
+    assert rel(m_.reshape(-1), q.mean.detach().numpy()) < 1e-10
+    assert rel(v_.reshape(-1), q.variance.detach().numpy()) < 1e-9

@@ -776,6 +776,52 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
     return VGGP_OK;
 }
 
+// Gridded read-out (include/vggp.h): t_d = sqrt(s_d) Q_d^T L0_d^{-1} C_d^T; mean = T1^T (beta / v) T2;
+// var = s1 s2 (kd1 kd2^T + (T1 o T1)^T W (T2 o T2)), W = D - 1 (literal) or 1/D - 1.
+extern "C" int vggp_readout(vggp_ctx* c, const double* C1, int64_t mv1, const double* C2, int64_t mv2, const double* kd1,
+                            const double* kd2, double* mean, double* var, int flags, void* stream) {
+    if (!c || !c->have_step) { vg_set_error("vggp_readout: no finished ELBO step"); return VGGP_ESTATE; }
+    VG_REQUIRE(C1 && C2 && kd1 && kd2 && mean && var && mv1 >= 1 && mv2 >= 1, "vggp_readout: bad argument");
+    VG_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long m1 = c->desc.m1, m2 = c->desc.m2;
+    const size_t need = (size_t)(3 * (m1 * mv1 + m2 * mv2) + 2 * m1 * mv2) * sizeof(double);
+    int rc = vg_ensure_misc(c, need);
+    if (rc) return rc;
+    double* p = (double*)c->misc;
+    double* X1 = p; p += m1 * mv1;
+    double* T1 = p; p += m1 * mv1;
+    double* S1 = p; p += m1 * mv1;
+    double* X2 = p; p += m2 * mv2;
+    double* T2 = p; p += m2 * mv2;
+    double* S2 = p; p += m2 * mv2;
+    double* U = p; p += m1 * mv2;
+    double* Uv = p;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    VG_HIP(vg_readout_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, (flags & VGGP_READOUT_LITERAL) ? 1 : 0, st));
+    VgGemmBatch g;
+    vg_gemm_init(&g);                                    // X_d = Linv0_d C_d^T            (m_d x mv_d)
+    vg_gemm_add(&g, d1.Linv0, m1, 1, C1, 1, m1, X1, (int)mv1, (int)m1, (int)mv1, (int)m1);
+    vg_gemm_add(&g, d2.Linv0, m2, 1, C2, 1, m2, X2, (int)mv2, (int)m2, (int)mv2, (int)m2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);                                    // T_d = Q_d^T X_d  (rows of QtPrev are the eigenvectors)
+    vg_gemm_add(&g, d1.QtPrev, m1, 1, X1, mv1, 1, T1, (int)mv1, (int)m1, (int)mv1, (int)m1);
+    vg_gemm_add(&g, d2.QtPrev, m2, 1, X2, mv2, 1, T2, (int)mv2, (int)m2, (int)mv2, (int)m2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_scale_sq_launch(T1, S1, m1 * mv1, st));
+    VG_HIP(vg_scale_sq_launch(T2, S2, m2 * mv2, st));
+    vg_gemm_init(&g);                                    // U = Wm T2, Uv = Wv (T2 o T2)   (m1 x mv2)
+    vg_gemm_add(&g, c->wq, m2, 1, T2, mv2, 1, U, (int)mv2, (int)m1, (int)mv2, (int)m2);
+    vg_gemm_add(&g, c->wq + m1 * m2, m2, 1, S2, mv2, 1, Uv, (int)mv2, (int)m1, (int)mv2, (int)m2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);                                    // mean = T1^T U, var' = (T1 o T1)^T Uv   (mv1 x mv2)
+    vg_gemm_add(&g, T1, 1, mv1, U, mv2, 1, mean, (int)mv2, (int)mv1, (int)mv2, (int)m1);
+    vg_gemm_add(&g, S1, 1, mv1, Uv, mv2, 1, var, (int)mv2, (int)mv1, (int)mv2, (int)m1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_readout_var_launch(c->theta, kd1, kd2, mv1, mv2, var, st));
+    return VGGP_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // exported building blocks
 extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double* x, int64_t n, const double* grid,

@@ -189,6 +189,9 @@ struct VgClearArgs { int* ptr[VG_CLEAR_MAX]; int nwords[VG_CLEAR_MAX]; int n; };
 hipError_t vg_clear_launch(const VgClearArgs* a, hipStream_t st);
 
 // q(v) / posterior helpers
+hipError_t vg_readout_weights_launch(const double* theta, const double* beta, const double* invD, double* w, long n, int literal,
+                                     hipStream_t st);
+hipError_t vg_readout_var_launch(const double* theta, const double* kd1, const double* kd2, long mv1, long mv2, double* var, hipStream_t st);
 hipError_t vg_scale_sq_launch(const double* in, double* out_sq, long n, hipStream_t st);
 hipError_t vg_qv_weights_launch(const double* theta, const double* beta, const double* invD, double* w_mean,
                                 long n, hipStream_t st, int e1 = 1, int e2 = 1);

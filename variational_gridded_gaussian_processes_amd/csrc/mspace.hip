@@ -309,6 +309,29 @@ hipError_t vg_qv_weights_launch(const double* theta, const double* beta, const d
     return hipGetLastError();
 }
 
+// read-out weights: w[0..n) = beta sqrt(s1 s2) / v (mean), w[n..2n) = D - 1 (literal reference) or 1/D - 1
+__global__ void vg_readout_weights_kernel(const double* theta, const double* beta, const double* invD, double* w, long n, int literal) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        w[i] = beta[i] * sqrt(theta[2] * theta[3]) / theta[4];
+        w[n + i] = literal ? 1.0 / invD[i] - 1.0 : invD[i] - 1.0;
+    }
+}
+hipError_t vg_readout_weights_launch(const double* theta, const double* beta, const double* invD, double* w, long n, int literal,
+                                     hipStream_t st) {
+    hipLaunchKernelGGL(vg_readout_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, beta, invD, w, n, literal);
+    return hipGetLastError();
+}
+// var[a][b] = s1 s2 (kd1[a] kd2[b] + var[a][b])
+__global__ void vg_readout_var_kernel(const double* theta, const double* kd1, const double* kd2, long mv1, long mv2, double* var) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < mv1 * mv2) var[i] = theta[2] * theta[3] * (kd1[i / mv2] * kd2[i % mv2] + var[i]);
+}
+hipError_t vg_readout_var_launch(const double* theta, const double* kd1, const double* kd2, long mv1, long mv2, double* var, hipStream_t st) {
+    hipLaunchKernelGGL(vg_readout_var_kernel, dim3((unsigned)((mv1 * mv2 + 255) / 256)), dim3(256), 0, st, theta, kd1, kd2, mv1, mv2, var);
+    return hipGetLastError();
+}
+
 // mode 0: x *= s1*s2 ; mode 1: x = s1*s2*(1 + x)
 __global__ void vg_scale_kernel(double* x, long n, const double* theta, int mode, int e1, int e2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -165,6 +165,19 @@ class Engine:
         check(self.lib.vggp_qv_cov(self._h, _ptr(cov), _stream()))
         return cov
 
+    def readout(self, C1: torch.Tensor, C2: torch.Tensor, kd1: torch.Tensor, kd2: torch.Tensor, literal: bool = True):
+        """Gridded read-out q(v) of B0 cell features from the inducing posterior of the last step (include/vggp.h):
+        C_d [mv_d, m_d] unit-outputscale cross-covariances, kd_d [mv_d] unit diagonals of Kvv_d -> mean, var [mv1, mv2]."""
+        C1, C2 = C1.to(self.device, torch.float64).contiguous(), C2.to(self.device, torch.float64).contiguous()
+        kd1, kd2 = kd1.to(self.device, torch.float64).contiguous(), kd2.to(self.device, torch.float64).contiguous()
+        if C1.shape[1] != self.m1 or C2.shape[1] != self.m2:
+            raise ValueError("C_d must be [mv_d, m_d]")
+        mean = torch.empty(C1.shape[0], C2.shape[0], dtype=torch.float64, device=self.device)
+        var = torch.empty_like(mean)
+        check(self.lib.vggp_readout(self._h, _ptr(C1), C1.shape[0], _ptr(C2), C2.shape[0], _ptr(kd1), _ptr(kd2), _ptr(mean),
+                                    _ptr(var), 1 if literal else 0, _stream()))
+        return mean, var
+
     def posterior_masked(self, x_star: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """posterior(x*) of the last masked step; x_star [ns, 2] -> mean[ns], var[ns]."""
         return self.posterior(x_star, _fn="vggp_posterior_masked")

@@ -411,6 +411,54 @@ class Matern12VFFGP(KroneckerStructure):
         return "vff", g1, g2
 
 
+def _b0_kvv_diag_unit(delta: float, ell: float) -> float:
+    """diag of the unit-outputscale B0 Gram matrix (gridded_kronecker_structure.py:341-394): ell^2 * 2 (e^{-d/l} + d/l - 1)."""
+    r = delta / ell
+    return ell * ell * 2.0 * (math.exp(-r) + r - 1.0)
+
+
+class GriddedMatern12VFFGP(Matern12VFFGP):
+    """gridded_kronecker_structure.py:470-654: the VFF model with a gridded read-out -- q_v() is the distribution of the
+    B0 cell features v on an nsplines x nsplines grid, obtained from the inducing posterior q(u) through p(v | u).
+    Mean and variance come from `vggp_readout` (Kronecker in the per-dimension cross-covariances :499-555); the variance is
+    the reference's own expression (:431, literal=True) unless literal=False is asked for."""
+
+    def __init__(self, X, y, nfrequencies: int, vffdim1lims, vffdim2lims, nsplines: int, griddim1lims, griddim2lims, **kw):
+        super().__init__(X, y, nfrequencies, vffdim1lims, vffdim2lims, **kw)
+        self.nsplines = nsplines
+        self.nknots = nsplines + 1
+        self.griddim1lims, self.griddim2lims = griddim1lims, griddim2lims
+        self.mesh_1 = torch.linspace(griddim1lims[0], griddim1lims[1], self.nknots)
+        self.mesh_2 = torch.linspace(griddim2lims[0], griddim2lims[1], self.nknots)
+        self.delta_1 = self.mesh_1[1] - self.mesh_1[0]
+        self.delta_2 = self.mesh_2[1] - self.mesh_2[0]
+
+    @staticmethod
+    def _Kvu_along_dim(mesh: torch.Tensor, a: float, omegas: torch.Tensor) -> torch.Tensor:
+        """:499-541: cell integrals of 1, cos(w (t - a)), sin(w (t - a)); (nsplines, 2M + 1), no hyper-parameter."""
+        me, om = mesh.double(), omegas.double()
+        k0 = torch.ones(me.shape[0] - 1, 1, dtype=torch.float64) * (me[1] - me[0])
+        kc = (torch.sin(om[1:] * (me[1:] - a)[:, None]) - torch.sin(om[1:] * (me[:-1] - a)[:, None])) / om[1:]
+        ks = -(torch.cos(om[1:] * (me[1:] - a)[:, None]) - torch.cos(om[1:] * (me[:-1] - a)[:, None])) / om[1:]
+        return torch.cat([k0, kc, ks], dim=1)
+
+    def q_u(self) -> MultivariateNormal:
+        """:613-624 -- the posterior over the Fourier features (what the parent class calls q_v)."""
+        return super().q_v()
+
+    def q_v(self, psd: bool = True, literal: bool = True) -> MultivariateNormal:
+        """:634-654 (mean and the diagonal of the covariance; flat index a * nsplines + b)."""
+        self._refresh()
+        C1 = self._Kvu_along_dim(self.mesh_1, self.dim1lims[0], self.omegas_1)
+        C2 = self._Kvu_along_dim(self.mesh_2, self.dim2lims[0], self.omegas_2)
+        l1 = self.kernel_1.base_kernel.lengthscale.reshape(()).item()
+        l2 = self.kernel_2.base_kernel.lengthscale.reshape(()).item()
+        kd1 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.delta_1.double()), l1), dtype=torch.float64)
+        kd2 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.delta_2.double()), l2), dtype=torch.float64)
+        mean, var = self._engine.readout(C1, C2, kd1, kd2, literal=literal)
+        return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
+
+
 class Matern12B1SplineASVGP(KroneckerStructure):
     """kronecker_structure.py:524-660: B1-spline (hat function) inducing features, Matern-1/2.
     Kuu_d = (A ell + B / ell + BC) / (2 s_d) (:560-614, tridiagonal), Kuf_d = hats(x) (:616-628)."""
