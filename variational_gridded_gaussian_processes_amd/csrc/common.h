@@ -129,6 +129,7 @@ struct VgEigJob {
     double* cp_dst = nullptr;        // (keeps the basis before last for the extrapolated warm start; scalar variant only)
     int* perm = nullptr;   // [m] scratch: rank of eigenpair i in decreasing order (scalar variant; null = leave unsorted)
     int fast_switch = 112; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
+    int polish = 1;        // dense phase: replace the remaining sweeps by a first-order polish when its a-priori bound allows
 };
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);

@@ -21,6 +21,10 @@
 #define VG_BJ_MAX_M 128            // block Jacobi up to this size, scalar cyclic Jacobi beyond
 #endif
 #define VG_EIG_DONE (1 << 30)   // progress word: rounds published | DONE
+#define VG_EIG_POLISH (1 << 28) // ... | POLISH: after the logged rotations, Q^T <- (I + E + E^2/2) Q^T with E in gwork
+#define VG_POLISH_EMAX 1e-3     // largest first-order rotation the polish accepts
+#define VG_POLISH_ROWS 64       // rows of E a replay workgroup stages in LDS at a time
+#define VG_POLISH_LD 129
 #define VG_EIG_LAG 9             // rounds whose log stores may still be in flight: vmcnt(16) with >= 2 VMEM ops per storing wave per round, +1
 #ifndef VG_SPARSE_OK
 #define VG_SPARSE_OK 1
@@ -153,7 +157,7 @@ __device__ __forceinline__ VgAngle vg_angle3(double gpp, double gqq, double gpq,
 // returns the buffer that holds G (packed, identity layout, diagonal included) when the phase ends; converged is set
 // when a whole sweep rotated nothing.  Wa must already hold the packed lower triangle.
 __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, double2* cs, double* Dd, int* nact_s, double thr,
-                                  int& nlog, int& sweeps, int& status, bool& converged) {
+                                  int& nlog, int& sweeps, int& status, bool& converged, bool& polished) {
     const int m = J.m, m2 = m + (m & 1), half = m2 >> 1, n1 = m2 - 1;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     // ---- block ownership (constant for the whole phase) ----
@@ -211,7 +215,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
     double* D0 = Dd;              // diag(G_R) for even R (position layout of round R)
     double* D1 = Dd + 256;
     // ---- prologue: rotations of round 0 from the diagonal blocks of the initial matrix ----
-    double eprime = 0.0;
+    double eprime = 0.0, tmax = 0.0;
     if (desig) {
         const double e = Wa[vg_sym(dpos, dqos)], dp = Wa[vg_tri(dpos) + dpos], dq = Wa[vg_tri(dqos) + dqos];
         const VgAngle a = vg_angle3(dp, dq, e, thr);
@@ -290,6 +294,12 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
                 eprime = a.rot ? 0.0 : e;
                 const unsigned long long bal = __ballot(a.rot);
                 if (lane == 0) nact_s[cur ^ 1] = __popcll(bal);
+                tmax = fmax(tmax, fabs(a.t));
+                if (r == n1 - 1) {                     // free screen for the polish: no large angle in the whole sweep
+                    const unsigned long long big = __ballot(tmax > VG_POLISH_EMAX);
+                    if (lane == 0) Dd[512] = big ? 1.0 : 0.0;
+                    tmax = 0.0;
+                }
             }
 #ifdef VG_EIG_STAMP
             VG_STAMP(fs0); fA += fs0 - fs1;
@@ -303,6 +313,57 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
         if (status) break;
         ++sweeps;
         if (active_rounds == 0) { converged = true; break; }
+        // ---- first-order polish instead of the remaining sweeps.  With every off-diagonal element small against the gap of
+        // its diagonal pair, the rotation that finishes the job is R = I + E + E^2/2, E_ij = g_ij / (g_ii - g_jj) (skew;
+        // R R^T = I + E^4/4), what is left behind is E Goff + (E Goff)^T to leading order, and the eigenvalues move by
+        // sum_j E_ij g_ij -- all bounded by ||E||_F ||Goff||_F.  When that bound is below the total the element-wise
+        // threshold admits anyway (m thr = tol ||G||_F), E goes to gwork and the replay workgroups apply R: the second
+        // dense sweep of a warm start on a well-separated spectrum (Matern kernels; ~127 rounds) becomes one scan.
+        // Clustered spectra (RBF: dozens of numerically null eigenvalues, |E| ~ 1 among them) never pass the test.
+        // Tried only when the next sweep would be another dense one (a sparse tail is cheaper than the polish itself).
+        if (J.polish && rotations >= switch_below && Dd[512] == 0.0) {
+            const double* Wc = (R & 1) ? Wb : Wa;           // off-diagonals of the current matrix, identity layout
+            const double* Dc = (R & 1) ? D1 : D0;           // its diagonal
+            double sE = 0.0, sG = 0.0, mE = 0.0;
+            for (int i = 1 + wave; i < m; i += (nthr >> 6)) {
+                const int ti = vg_tri(i);
+                const double di = Dc[i];
+                for (int j = lane; j < i; j += 64) {
+                    const double g = Wc[ti + j];
+                    sG += g * g;
+                    if (fabs(g) > thr) {
+                        const double e = g / (di - Dc[j]);
+                        sE += e * e;
+                        mE = fmax(mE, fabs(e));
+                    }
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                sE += __shfl_xor(sE, off); sG += __shfl_xor(sG, off); mE = fmax(mE, __shfl_xor(mE, off));
+            }
+            double* rs = Dd + 520;
+            if (lane == 0) { rs[wave] = sE; rs[16 + wave] = sG; rs[32 + wave] = mE; }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            sE = sG = mE = 0.0;
+            for (int w = 0; w < (nthr >> 6); ++w) { sE += rs[w]; sG += rs[16 + w]; mE = fmax(mE, rs[32 + w]); }
+            const double budget = (double)m * thr;
+            if (mE <= VG_POLISH_EMAX && 4.0 * sE * sG <= budget * budget) {      // NaN / inf (equal diagonals) fail both
+                double* E = J.gwork;
+                for (int i = wave; i < m; i += (nthr >> 6)) {
+                    const int ti = vg_tri(i);
+                    const double di = Dc[i];
+                    for (int j = lane; j <= i; j += 64) {
+                        const double g = (j < i) ? Wc[ti + j] : 0.0;
+                        const double e = (j < i && fabs(g) > thr) ? g / (di - Dc[j]) : 0.0;
+                        __hip_atomic_store(&E[i * m + j], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (j < i) __hip_atomic_store(&E[j * m + i], -e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                polished = true;
+                converged = true;
+                break;
+            }
+        }
         if (rotations < switch_below) break;
         if (sweeps >= VG_EIG_MAXSWEEP) status = VGGP_ENOCONV;
     }
@@ -380,11 +441,11 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
     const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
     int nlog = 0, sweeps = 0, status = 0;
-    bool converged = false;
+    bool converged = false, polished = false;
     RT(1);
     if (INLDS && fast)           // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
         W = vg_jacobi_fast(J, W, W + ((m2 * (m2 + 1)) >> 1), cs, reinterpret_cast<double*>(pq), nact_s, thr, nlog, sweeps,
-                           status, converged);
+                           status, converged, polished);
 
     RT(2);
     // round-independent block -> thread map: canonical blocks (al >= be) enumerated row by row, dealt round-robin
@@ -566,7 +627,8 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
         J.counters[1] = sweeps;
         J.counters[2] = status;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE | (polished ? VG_EIG_POLISH : 0), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     RT(4);
 #ifdef VG_EIG_STAMP
@@ -608,6 +670,7 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
     const int jj = wave * 4 + (lane & 3);                   // this lane's column inside the block
     const bool colwave = wave * 4 < VG_RP_COLS;              // waves beyond the tile only help with the loads
     int consumed = 0;
+    bool polish = false;
     for (;;) {
         // one lane polls the producer's progress word (relaxed, agent scope), then the workgroup rendezvous
         if (tid == 0) {
@@ -625,7 +688,8 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
         const int pw = s_sync[0];
         const bool done = (pw & VG_EIG_DONE) != 0;
         if (pw & 0x20000000) break;                          // producer never showed up (timeout)
-        const int published = pw & 0x1fffffff;
+        polish = done && (pw & VG_EIG_POLISH);
+        const int published = pw & 0x0fffffff;
         const int nr = min(rounds_per_chunk, published - consumed);
         if (nr > 0) {
             for (int idx = tid; idx < nr * half; idx += nthr) {
@@ -674,6 +738,39 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
         if (done && consumed >= published) break;
     }
     __syncthreads();
+    if (polish && VG_RP_COLS == 16) {
+        // T <- T + E (T + E T / 2): two passes over E (the producer left it in gwork), VG_POLISH_ROWS rows staged at a time;
+        // thread = (row in the stage, column of the slice), 16 lanes share an E element (broadcast)
+        double* T1 = reinterpret_cast<double*>(rchunk + 1024);
+        double* Es = T1 + (long)m2 * VG_RP_LD;
+        const int il = tid >> 4, jc = tid & 15;
+        double keep[(128 + VG_POLISH_ROWS - 1) / VG_POLISH_ROWS];
+        for (int pass = 0; pass < 2; ++pass) {
+            const double* Tin = pass ? T1 : T;
+            for (int h = 0; h * VG_POLISH_ROWS < m; ++h) {
+                const int r0 = h * VG_POLISH_ROWS, nr_ = min(VG_POLISH_ROWS, m - r0);
+                for (int idx = tid; idx < nr_ * m; idx += nthr) {
+                    const int rr_ = idx / m, cc_ = idx - rr_ * m;
+                    Es[rr_ * VG_POLISH_LD + cc_] =
+                        __hip_atomic_load(&J.gwork[(long)(r0 + rr_) * m + cc_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (il < nr_) {
+                    double acc = 0.0;
+                    const double* er = Es + il * VG_POLISH_LD;
+#pragma unroll 8
+                    for (int k = 0; k < m; ++k) acc = fma(er[k], Tin[k * VG_RP_LD + jc], acc);
+                    const double t0 = T[(r0 + il) * VG_RP_LD + jc];
+                    if (pass == 0) T1[(r0 + il) * VG_RP_LD + jc] = t0 + 0.5 * acc;
+                    else keep[h] = t0 + acc;
+                }
+                __syncthreads();
+            }
+        }
+        for (int h = 0; h * VG_POLISH_ROWS < m; ++h)
+            if (il < min(VG_POLISH_ROWS, m - h * VG_POLISH_ROWS)) T[(h * VG_POLISH_ROWS + il) * VG_RP_LD + jc] = keep[h];
+        __syncthreads();
+    }
     for (int idx = tid; idx < m * VG_RP_COLS; idx += nthr) {
         const int i = idx >> csh, j = j0 + (idx & (VG_RP_COLS - 1));
         if (j < m) {
@@ -1100,7 +1197,7 @@ __device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int*
         const int pw = s_sync[0];
         if (pw & 0x20000000) break;
         const bool done = (pw & VG_EIG_DONE) != 0;
-        const int published = pw & 0x1fffffff;
+        const int published = pw & 0x0fffffff;
         if (published > consumed) {
             const double* src = ulog + (long)consumed * npair * 1024;
             for (int idx = tid; idx < npair * 1024; idx += nthr)
@@ -1191,6 +1288,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
     a.njobs = njobs;
     static const char* fs_env = getenv("VGGP_EIG_FAST_SWITCH");      // tuning / A-B switch (0 disables the dense phase)
     static const char* tol_env = getenv("VGGP_EIG_TOL");
+    static const bool no_polish = getenv("VGGP_EIG_NO_POLISH") != nullptr;
     size_t lds = 0;
     int maxm2 = 0;
     for (int j = 0; j < njobs; ++j) maxm2 = jobs[j].m + 1 > maxm2 ? jobs[j].m + 1 : maxm2;
@@ -1202,6 +1300,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
         a.job[j] = jobs[j];
         if (fs_env) a.job[j].fast_switch = atoi(fs_env);
         if (tol_env) a.job[j].tol = atof(tol_env);
+        if (no_polish) a.job[j].polish = 0;
         const int m = jobs[j].m;
         if (m < 1 || m > 256) return hipErrorInvalidValue;
         const int m2 = m + (m & 1);
@@ -1210,6 +1309,8 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
         a.fast[j] = a.use_lds[j] && !jobs[j].block && a.job[j].fast_switch > 0 && m2 >= 16 && m2 <= 128;
         if (a.fast[j]) need *= 2;
         size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
+        if (a.fast[j] && a.job[j].polish)      // + T1 and the staged rows of E
+            rp += (size_t)m2 * VG_RP_LD * sizeof(double) + (size_t)VG_POLISH_ROWS * VG_POLISH_LD * sizeof(double);
         if (jobs[j].block && m <= VG_BJ_MAX_M) {
             const size_t nb = 2 * ((m + 31) / 32), Mp = 16 * nb, np = nb / 2;
             need = (((Mp * (Mp + 1) / 2 + 1) & ~size_t(1)) + np * VG_BJ_SLOT) * sizeof(double);
