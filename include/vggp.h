@@ -98,7 +98,7 @@ typedef struct vggp_info {
     int32_t sweeps1, sweeps2;     /* Jacobi sweeps used                               */
     int32_t rounds1, rounds2;     /* Jacobi rotation rounds applied                   */
     int32_t status;               /* 0 or a VGGP_E* code detected on the device       */
-    int32_t reserved;
+    int32_t polished;             /* bit d-1: dimension d's eigensolver ended in a first-order polish */
 } vggp_info;
 
 int         vggp_version(void);

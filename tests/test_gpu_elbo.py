@@ -339,3 +339,25 @@ def test_gridded_readout_vs_oracle(engine, basis, literal):
     mean, var = engine.readout(torch.tensor(C1), torch.tensor(C2), torch.tensor(kd1), torch.tensor(kd2), literal=literal)
     assert mean.shape == (7, 5)
     assert rel(mean.cpu().numpy(), rm) < RTOL and rel(var.cpu().numpy(), rv) < 1e-6
+
+
+def test_polish_ends_warm_matern_steps(engine):
+    """Eigensolver: on a well-separated spectrum (Matern) a warm-started step ends in the first-order polish instead of a
+    second dense sweep (eigh.hip; the a-priori bound keeps the result inside the same tolerance), and never on RBF's
+    clustered spectrum.  Values and gradients of the polished steps are checked against the oracle."""
+    n1 = n2 = 96
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    g = np.linspace(0, 1, 64)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    for kind, expect in (("matern32", True), ("rbf", False)):
+        engine.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=True)
+        yy = engine.sumsq(Y)
+        f1, f2 = Kr.Factor("points", kind, g, x1), Kr.Factor("points", kind, g, x2)
+        hits = 0
+        for t in range(8):
+            theta = [0.3 * 1.01 ** t, 0.25 * 1.01 ** t, 0.9, 1.2, 0.02]
+            elbo, grad, info = engine.elbo_step(Y, yy, theta)
+            st = Kr.elbo_step(y.reshape(n2, n1), f1, f2, theta)
+            assert rel(elbo, st.elbo) < RTOL and rel(grad, st.grad) < 1e-6, (kind, t)
+            hits += int(all(info["polished"]))
+        assert (hits >= 3) == expect, (kind, hits)

@@ -34,7 +34,7 @@ class Info(C.Structure):
     _fields_ = [("jitter1", C.c_double), ("jitter2", C.c_double),
                 ("sweeps1", C.c_int32), ("sweeps2", C.c_int32),
                 ("rounds1", C.c_int32), ("rounds2", C.c_int32),
-                ("status", C.c_int32), ("reserved", C.c_int32)]
+                ("status", C.c_int32), ("polished", C.c_int32)]
 
 
 # every symbol include/vggp.h declares: name -> (restype, argtypes)

@@ -574,7 +574,8 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         info->jitter1 = c->h_out->jitter[0]; info->jitter2 = c->h_out->jitter[1];
         info->sweeps1 = c->h_out->counters[0][1]; info->sweeps2 = c->h_out->counters[1][1];
         info->rounds1 = c->h_out->counters[0][0]; info->rounds2 = c->h_out->counters[1][0];
-        info->status = status; info->reserved = 0;
+        info->status = status;
+        info->polished = ((c->h_out->counters[0][3] >> 28) & 1) | (((c->h_out->counters[1][3] >> 28) & 1) << 1);
     }
     if (status) {          // the bases written by this step are not trustworthy: the next step starts cold
         c->warm_run = 0;

@@ -400,7 +400,7 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     if (info) {
         info->jitter1 = c->h_out->jitter[0]; info->jitter2 = c->h_out->jitter[1];
         info->sweeps1 = info->sweeps2 = info->rounds1 = info->rounds2 = 0;
-        info->status = status; info->reserved = 0;
+        info->status = status; info->polished = 0;
     }
     if (status) { vg_set_error("masked step: a factor is not positive definite"); return VGGP_ENOTPD; }
     c->have_masked = true;

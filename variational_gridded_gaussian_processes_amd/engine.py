@@ -151,7 +151,7 @@ class Engine:
     @staticmethod
     def _info(i: Info) -> dict:
         return dict(jitter=(i.jitter1, i.jitter2), sweeps=(i.sweeps1, i.sweeps2), rounds=(i.rounds1, i.rounds2),
-                    status=i.status)
+                    status=i.status, polished=(bool(i.polished & 1), bool(i.polished & 2)))
 
     def qv(self) -> Tuple[torch.Tensor, torch.Tensor]:
         mean = torch.empty(self.m1, self.m2, dtype=torch.float64, device=self.device)
