@@ -17,7 +17,7 @@
 #include <algorithm>
 
 #define VG_MB 128                 // panel width of the blocked Cholesky
-#define VG_MD_NPART 64            // partial sums per reduction job
+#define VG_MD_NPART 256           // partial sums per reduction job
 #define VG_MD_MAXJOBS 24
 
 // ---- small kernels -------------------------------------------------------------------------------------------------
@@ -57,11 +57,21 @@ __global__ void vgm_coldot_kernel(const double* Xa, const double* Xb, int m, lon
 }
 
 // wcol[i] = sum_j W[j][i] v[j]  (n1 outputs) ; wrow[j] = sum_i W[j][i] u[i]  (n2 outputs)
-__global__ void vgm_wcol_kernel(const double* W, const double* v, long n1, long n2, double* wcol) {
+// two stages (row slabs, then a deterministic sum over the slabs): a single pass with one thread per column is 8 workgroups
+// walking 2048 rows each -- 0.5 ms of pure latency at n = 2048
+__global__ void vgm_wcol_part_kernel(const double* W, const double* v, long n1, long n2, int nslab, double* part) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const long per = (n2 + nslab - 1) / nslab, j0 = blockIdx.y * per, j1 = j0 + per < n2 ? j0 + per : n2;
+    double s = 0.0;
+    for (long j = j0; j < j1; ++j) s += W[j * n1 + i] * v[j];
+    part[(long)blockIdx.y * n1 + i] = s;
+}
+__global__ void vgm_wcol_sum_kernel(const double* part, long n1, int nslab, double* wcol) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n1) return;
     double s = 0.0;
-    for (long j = 0; j < n2; ++j) s += W[j * n1 + i] * v[j];
+    for (int k = 0; k < nslab; ++k) s += part[(long)k * n1 + i];
     wcol[i] = s;
 }
 __global__ __launch_bounds__(256) void vgm_wrow_kernel(const double* W, const double* u, long n1, long n2, double* wrow) {
@@ -318,7 +328,13 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     VGM_LAUNCH1D(vgm_coldot_kernel, n2, st, B2, B2, (int)m2, n2, w.nb2);
     VGM_LAUNCH1D(vgm_coldot_kernel, n1, st, V1, B1, (int)m1, n1, w.hv1);
     VGM_LAUNCH1D(vgm_coldot_kernel, n2, st, V2, B2, (int)m2, n2, w.hv2);
-    VGM_LAUNCH1D(vgm_wcol_kernel, n1, st, W, w.nb2, n1, n2, w.wn2);
+    {
+        const long mm = m2 * m2;                                // w.T ([m2 m2][n1], written by the assembly below) is the scratch
+        const int nslab = (int)(mm < 64 ? mm : 64);
+        hipLaunchKernelGGL(vgm_wcol_part_kernel, dim3((unsigned)((n1 + 255) / 256), (unsigned)nslab), dim3(256), 0, st, W, w.nb2,
+                           n1, n2, nslab, w.T);
+        VGM_LAUNCH1D(vgm_wcol_sum_kernel, n1, st, w.T, n1, nslab, w.wn2);
+    }
     hipLaunchKernelGGL(vgm_wrow_kernel, dim3((unsigned)n2), dim3(256), 0, st, W, w.nb1, n1, n2, w.wn1);
     // assembly
     VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * n2, st, B2, B2, (int)m2, (int)m2, n2, w.PP2);
