@@ -361,3 +361,26 @@ def test_polish_ends_warm_matern_steps(engine):
             assert rel(elbo, st.elbo) < RTOL and rel(grad, st.grad) < 1e-6, (kind, t)
             hits += int(all(info["polished"]))
         assert (hits >= 3) == expect, (kind, hits)
+
+
+def test_polish_odd_m_vff_trajectory(engine):
+    """The polish on an odd-sized problem (VFF: m = 2M + 1 = 21, padded to 22 inside the eigensolver), warm trajectory."""
+    n1, n2, M = 80, 72, 10
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    a, b = -0.1, 1.1
+    g = np.concatenate([[a, b], D.vff_omegas(M, a, b).double().numpy()])
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    engine.plan("matern12", "vff", g, x1, "matern12", "vff", g, x2, warm_start=True)
+    yy = engine.sumsq(Y)
+    f1, f2 = Kr.Factor("vff", "matern12", g, x1), Kr.Factor("vff", "matern12", g, x2)
+    hits = 0
+    for t in range(8):
+        theta = [0.3 * 1.01 ** t, 0.25 * 0.99 ** t, 0.9, 1.2, 0.02]
+        elbo, grad, info = engine.elbo_step(Y, yy, theta)
+        st = Kr.elbo_step(y.reshape(n2, n1), f1, f2, theta)
+        assert rel(elbo, st.elbo) < RTOL and rel(grad, st.grad) < 1e-6, t
+        hits += int(any(info["polished"]))
+    mean, var = engine.qv()
+    qm, qv_ = Kr.q_v(st)
+    assert rel(mean.cpu().numpy(), qm) < 1e-6 and rel(var.cpu().numpy(), qv_) < 1e-6
+    assert hits >= 1
