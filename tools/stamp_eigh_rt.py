@@ -18,9 +18,10 @@ G = Qt @ (d1.B @ d1.B.T) @ Qt.T
 Gd = torch.tensor(G, device="cuda")
 for _ in range(3):
     lam, Q2, sw = e.eigh(Gd)
-buf = (C.c_uint64 * 300)()
+nb = m * m + 16
+buf = (C.c_uint64 * nb)()
 e.lib.vggp_debug_read_misc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-e.lib.vggp_debug_read_misc(e._h, buf, 300 * 8)
-t = np.array(list(buf))[256:262].astype(float) * 10.0 / 1e3      # us
+e.lib.vggp_debug_read_misc(e._h, buf, nb * 8)
+t = np.array(list(buf))[m * m + 8:m * m + 14].astype(float) * 10.0 / 1e3      # us (stamps sit past the polish matrix E)
 print("sweeps", sw, "phases (us): load+norm %.1f  dense phase %.1f  sparse-setup+sparse phase %.1f  sort+lam+DONE %.1f  | producer total %.1f  consumer-0 done at %.1f"
       % (t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[4] - t[0], t[5] - t[0]))

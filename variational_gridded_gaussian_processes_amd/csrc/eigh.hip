@@ -23,8 +23,7 @@
 #define VG_EIG_DONE (1 << 30)   // progress word: rounds published | DONE
 #define VG_EIG_POLISH (1 << 28) // ... | POLISH: after the logged rotations, Q^T <- (I + E + E^2/2) Q^T with E in gwork
 #define VG_POLISH_EMAX 1e-3     // largest first-order rotation the polish accepts
-#define VG_POLISH_ROWS 64       // rows of E a replay workgroup stages in LDS at a time
-#define VG_POLISH_LD 129
+typedef double vg_bd4 __attribute__((ext_vector_type(4)));
 #define VG_EIG_LAG 9             // rounds whose log stores may still be in flight: vmcnt(16) with >= 2 VMEM ops per storing wave per round, +1
 #ifndef VG_SPARSE_OK
 #define VG_SPARSE_OK 1
@@ -325,17 +324,20 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
             const double* Wc = (R & 1) ? Wb : Wa;           // off-diagonals of the current matrix, identity layout
             const double* Dc = (R & 1) ? D1 : D0;           // its diagonal
             double sE = 0.0, sG = 0.0, mE = 0.0;
+            double* E = J.gwork;                            // strict lower triangle only, row-major, stored speculatively
             for (int i = 1 + wave; i < m; i += (nthr >> 6)) {
                 const int ti = vg_tri(i);
                 const double di = Dc[i];
                 for (int j = lane; j < i; j += 64) {
                     const double g = Wc[ti + j];
+                    double e = 0.0;
                     sG += g * g;
                     if (fabs(g) > thr) {
-                        const double e = g / (di - Dc[j]);
+                        e = g / (di - Dc[j]);
                         sE += e * e;
                         mE = fmax(mE, fabs(e));
                     }
+                    __hip_atomic_store(&E[i * m + j], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -348,17 +350,6 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
             for (int w = 0; w < (nthr >> 6); ++w) { sE += rs[w]; sG += rs[16 + w]; mE = fmax(mE, rs[32 + w]); }
             const double budget = (double)m * thr;
             if (mE <= VG_POLISH_EMAX && 4.0 * sE * sG <= budget * budget) {      // NaN / inf (equal diagonals) fail both
-                double* E = J.gwork;
-                for (int i = wave; i < m; i += (nthr >> 6)) {
-                    const int ti = vg_tri(i);
-                    const double di = Dc[i];
-                    for (int j = lane; j <= i; j += 64) {
-                        const double g = (j < i) ? Wc[ti + j] : 0.0;
-                        const double e = (j < i && fabs(g) > thr) ? g / (di - Dc[j]) : 0.0;
-                        __hip_atomic_store(&E[i * m + j], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (j < i) __hip_atomic_store(&E[j * m + i], -e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
                 polished = true;
                 converged = true;
                 break;
@@ -388,7 +379,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
 }
 
 #ifdef VG_EIG_RT
-#define RT(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); reinterpret_cast<unsigned long long*>(J.gwork)[256 + (i)] = t_; } } while (0)
+#define RT(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); reinterpret_cast<unsigned long long*>(J.gwork)[(long)J.m * J.m + 8 + (i)] = t_;   /* past the polish matrix E */ } } while (0)
 #else
 #define RT(i)
 #endif
@@ -739,36 +730,57 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
     }
     __syncthreads();
     if (polish && VG_RP_COLS == 16) {
-        // T <- T + E (T + E T / 2): two passes over E (the producer left it in gwork), VG_POLISH_ROWS rows staged at a time;
-        // thread = (row in the stage, column of the slice), 16 lanes share an E element (broadcast)
+        // T <- T + E (T + E T / 2) on the matrix cores: wave w owns rows 16w .. 16w+15 of the slice; its 16 x 128 block of E
+        // (the producer left E in gwork) is loaded ONCE, straight into MFMA A-operand registers, and serves both passes;
+        // the B operands are single LDS reads of T (pass 1) and T1 (pass 2).  v_mfma_f64_16x16x4: lane (fi, fk) supplies
+        // A[fi][4 kk + fk], B[4 kk + fk][fi] and receives D[fk + 4 r][fi].
         double* T1 = reinterpret_cast<double*>(rchunk + 1024);
-        double* Es = T1 + (long)m2 * VG_RP_LD;
-        const int il = tid >> 4, jc = tid & 15;
-        double keep[(128 + VG_POLISH_ROWS - 1) / VG_POLISH_ROWS];
-        for (int pass = 0; pass < 2; ++pass) {
-            const double* Tin = pass ? T1 : T;
-            for (int h = 0; h * VG_POLISH_ROWS < m; ++h) {
-                const int r0 = h * VG_POLISH_ROWS, nr_ = min(VG_POLISH_ROWS, m - r0);
-                for (int idx = tid; idx < nr_ * m; idx += nthr) {
-                    const int rr_ = idx / m, cc_ = idx - rr_ * m;
-                    Es[rr_ * VG_POLISH_LD + cc_] =
-                        __hip_atomic_load(&J.gwork[(long)(r0 + rr_) * m + cc_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                if (il < nr_) {
-                    double acc = 0.0;
-                    const double* er = Es + il * VG_POLISH_LD;
-#pragma unroll 8
-                    for (int k = 0; k < m; ++k) acc = fma(er[k], Tin[k * VG_RP_LD + jc], acc);
-                    const double t0 = T[(r0 + il) * VG_RP_LD + jc];
-                    if (pass == 0) T1[(r0 + il) * VG_RP_LD + jc] = t0 + 0.5 * acc;
-                    else keep[h] = t0 + acc;
-                }
-                __syncthreads();
+        const int fi = lane & 15, fk = lane >> 4, row0 = wave * 16;
+        const bool act = row0 < m;
+        double ea[32];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = kk * 4 + fk;
+            const int i = row0 + fi;
+            ea[kk] = 0.0;                                   // E is skew: the producer stored the strict lower triangle
+            if (act && i < m && k < m && k != i) {
+                const double v = __hip_atomic_load(&J.gwork[k < i ? (long)i * m + k : (long)k * m + i], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                ea[kk] = k < i ? v : -v;
             }
         }
-        for (int h = 0; h * VG_POLISH_ROWS < m; ++h)
-            if (il < min(VG_POLISH_ROWS, m - h * VG_POLISH_ROWS)) T[(h * VG_POLISH_ROWS + il) * VG_RP_LD + jc] = keep[h];
+        vg_bd4 keep = {0.0, 0.0, 0.0, 0.0};
+        for (int pass = 0; pass < 2; ++pass) {
+            const double* Tin = pass ? T1 : T;
+            if (act) {
+                vg_bd4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    const int k = kk * 4 + fk;
+                    if (kk * 4 < m2) {                                   // wave-uniform
+                        const double bv = k < m2 ? Tin[k * VG_RP_LD + fi] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ea[kk], bv, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = row0 + fk + 4 * r;
+                    if (i < m2) {
+                        const double t0 = T[i * VG_RP_LD + fi];
+                        if (pass == 0) T1[i * VG_RP_LD + fi] = t0 + 0.5 * acc[r];
+                        else keep[r] = t0 + acc[r];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row0 + fk + 4 * r;
+                if (i < m2) T[i * VG_RP_LD + fi] = keep[r];
+            }
+        }
         __syncthreads();
     }
     for (int idx = tid; idx < m * VG_RP_COLS; idx += nthr) {
@@ -803,7 +815,6 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
 //   * the four U of an outer round are logged (write-through) for the replay workgroups, which apply
 //     Qt[IJ, cols] <- U^T Qt[IJ, cols] with MFMA on their 16-column tile.
 // Per outer sweep: 31 + 16 (nb - 2) = m-ish inner rounds, each ~4x cheaper than a full-matrix round, plus nb - 1 applies.
-typedef double vg_bd4 __attribute__((ext_vector_type(4)));
 #define VG_BJ_SLOT (2 * 32 * 32)                // doubles per pair slot: S then U
 // 32 x 32 tiles are stored with row stride 32 and the column XOR-swizzled by 16 on odd rows: a half-wave that touches
 // rows {r, r+1} x 16 columns (every S / U access pattern here) then hits 32 distinct 8-byte banks (stride 33 gave
@@ -1309,8 +1320,8 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
         a.fast[j] = a.use_lds[j] && !jobs[j].block && a.job[j].fast_switch > 0 && m2 >= 16 && m2 <= 128;
         if (a.fast[j]) need *= 2;
         size_t rp = (size_t)m2 * VG_RP_LD * sizeof(double) + VG_RP_CHUNK_BYTES + 4096;
-        if (a.fast[j] && a.job[j].polish)      // + T1 and the staged rows of E
-            rp += (size_t)m2 * VG_RP_LD * sizeof(double) + (size_t)VG_POLISH_ROWS * VG_POLISH_LD * sizeof(double);
+        if (a.fast[j] && a.job[j].polish)      // + T1
+            rp += (size_t)m2 * VG_RP_LD * sizeof(double);
         if (jobs[j].block && m <= VG_BJ_MAX_M) {
             const size_t nb = 2 * ((m + 31) / 32), Mp = 16 * nb, np = nb / 2;
             need = (((Mp * (Mp + 1) / 2 + 1) & ~size_t(1)) + np * VG_BJ_SLOT) * sizeof(double);
