@@ -83,7 +83,7 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
 extern "C" int vggp_destroy(vggp_ctx* c) {
     if (!c) return VGGP_OK;
     (void)hipSetDevice(c->device);
-    for (int i = 0; i < 8; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    for (int i = 0; i < 12; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
     vg_masked_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->arena) (void)hipFree(c->arena);
@@ -253,6 +253,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     c->planned = false;
     graphs_clear(c);
     c->warm_run = 0;
+    c->refine_next = false;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -400,7 +401,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
 }
 
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
-                          bool from_slabs = false, bool extrap = false) {
+                          bool from_slabs = false, bool extrap = false, bool refine = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -432,16 +433,54 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_add(&g, d.TM, d.m, 1, extrap ? d.F : d.QtPrev, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
         }
         VG_HIP(vg_gemm_launch(&g, st));
+        // First-order refinement of the start basis (used while the previous step ended in the polish, i.e. on
+        // well-separated spectra): S' = (I + E + E^2/2) S with E from Gw = S G S^T, then Gw' = S' G S'^T.  Five short
+        // launches that replace the one dense Jacobi sweep (127 rounds) the polish still needed: the eigensolver
+        // then only scans, and the replay workgroups apply the final polish.  A start that is too far off (|E| > 1e-3)
+        // gets E = 0 from the kernel and the eigensolver proceeds as usual.
+        if (refine) {
+            VgRefineJob rj[2];
+            for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, 0.0}; }
+            VG_HIP(vg_refine_launch(rj, 2, st));                                        // E -> U, I + E -> TH
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                const double* S0 = extrap ? d.F : d.QtPrev;
+                vg_gemm_add(&g, d.TH, d.m, 1, S0, d.m, 1, d.E, d.m, d.m, d.m, d.m);    // (I + E) S -> E
+                vg_gemm_add(&g, d.U, d.m, 1, d.U, d.m, 1, d.X, d.m, d.m, d.m, d.m);     // E E -> X
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                const double* S0 = extrap ? d.F : d.QtPrev;
+                vg_gemm_add(&g, d.X, d.m, 1, S0, d.m, 1, d.E, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 0.5, 1);   // += E^2 S / 2
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                vg_gemm_add(&g, d.E, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                vg_gemm_add(&g, d.TM, d.m, 1, d.E, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+        }
     }
     VG_MARK(7);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? (extrap ? d.F : d.QtPrev) : nullptr, d.gwork, d.rotlog, d.roundlog,
+        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? (refine ? d.E : (extrap ? d.F : d.QtPrev)) : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
                          (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
         ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
         ej[k].perm = d.perm;
         ej[k].cp_src = d.QtPrev; ej[k].cp_dst = d.QtPrev2;      // the basis before last, for the next extrapolation
+        ej[k].polish0 = (warm && refine) ? 1 : 0;
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -507,7 +546,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // ---- HIP-graph cache: the launch sequence of a step is fixed for a plan, so it is captured once per
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
-       VG_G_STEP_WARM_X, VG_G_COUNT };      // _X: warm start from the extrapolated basis
+       VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_COUNT };
+// _X: warm start from the extrapolated basis; _XR: ... refined to first order before the eigensolver (see finish_enqueue)
 
 static void graphs_clear(vggp_ctx* c) {
     for (int i = 0; i < VG_G_COUNT; ++i) {
@@ -537,6 +577,11 @@ static int run_graph(vggp_ctx* c, int which, const VgGraphKey& key, hipStream_t 
 }
 
 // extrapolated warm start: needs the bases of the last two steps (scalar Jacobi variant; VGGP_NO_EXTRAP=1 switches it off)
+static bool vg_refine(const vggp_ctx* c, bool extrap) {
+    static const bool off = getenv("VGGP_NO_REFINE") != nullptr;
+    return !off && extrap && c->refine_next;
+}
+
 static bool vg_extrapolate(const vggp_ctx* c) {
     static const bool off = getenv("VGGP_NO_EXTRAP") != nullptr;
     return !off && c->desc.warm_start && !(c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) && c->d[0].have_prev && c->d[1].have_prev &&
@@ -577,6 +622,7 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         info->status = status;
         info->polished = ((c->h_out->counters[0][3] >> 28) & 1) | (((c->h_out->counters[1][3] >> 28) & 1) << 1);
     }
+    c->refine_next = !status && ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1);
     if (status) {          // the bases written by this step are not trustworthy: the next step starts cold
         c->warm_run = 0;
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
@@ -624,8 +670,9 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{nullptr, payload, yy_total};
     const bool extrap = vg_extrapolate(c);       // same state as at the matching vggp_elbo_partials call
-    rc = run_graph(c, warm ? (extrap ? VG_G_FINISH_WARM_X : VG_G_FINISH_WARM) : VG_G_FINISH_COLD, key, st,
-                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap); });
+    const bool refine = warm && vg_refine(c, extrap);
+    rc = run_graph(c, warm ? (extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM) : VG_G_FINISH_COLD, key, st,
+                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap, refine); });
     if (rc) return rc;
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
@@ -642,9 +689,10 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{Y, c->payload, yy_total};
     const bool extrap = vg_extrapolate(c);
-    rc = run_graph(c, warm ? (extrap ? VG_G_STEP_WARM_X : VG_G_STEP_WARM) : VG_G_STEP_COLD, key, st, [&] {
+    const bool refine = warm && vg_refine(c, extrap);
+    rc = run_graph(c, warm ? (extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM) : VG_G_STEP_COLD, key, st, [&] {
         const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine);
     });
     if (rc) return rc;
     c->have_partials = true;

@@ -130,7 +130,12 @@ struct VgEigJob {
     int* perm = nullptr;   // [m] scratch: rank of eigenpair i in decreasing order (scalar variant; null = leave unsorted)
     int fast_switch = 112; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
     int polish = 1;        // dense phase: replace the remaining sweeps by a first-order polish when its a-priori bound allows
+    int polish0 = 0;       // also try the polish before the first sweep (the start basis was refined by vg_refine_launch)
 };
+// First-order refinement of a warm start (eigh.hip): from Gw = S G S^T, E_ij = g_ij / (g_ii - g_jj) for the elements above
+// the eigensolver's threshold; outputs E and R1 = I + E (both [m][m]); E = 0, R1 = I when some |E_ij| > 1e-3.
+struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol; };
+hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st);
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);
 hipError_t vg_eigh_setup();

@@ -58,8 +58,9 @@ struct vggp_ctx {
     // directions (uploads / all-reduce issued by torch on stream 0 before, q(v) / posterior calls after).
     hipStream_t own_stream = nullptr;
     bool use_graph = true;
-    hipGraphExec_t gexec[8] = {};
-    VgGraphKey gkey[8];
+    hipGraphExec_t gexec[12] = {};
+    VgGraphKey gkey[12];
+    bool refine_next = false;         // the last step ended in the polish in both dimensions: refine the next start basis
     int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
     bool prof = false;

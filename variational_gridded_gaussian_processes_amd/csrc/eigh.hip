@@ -153,6 +153,39 @@ __device__ __forceinline__ VgAngle vg_angle3(double gpp, double gqq, double gpq,
     return a;
 }
 
+// One scan of the strict lower triangle (identity layout, diagonal in Dc): E_ij = g_ij / (g_ii - g_jj) for the elements
+// above thr, stored speculatively (strict lower triangle, row-major, write-through) in J.gwork; returns whether the polish
+// R = I + E + E^2/2 may replace the remaining sweeps (see vg_jacobi_fast).  rs: 48 doubles of LDS scratch.
+__device__ bool vg_polish_scan(const VgEigJob& J, const double* Wc, const double* Dc, double thr, double* rs) {
+    const int m = J.m, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    double sE = 0.0, sG = 0.0, mE = 0.0;
+    double* E = J.gwork;
+    for (int i = 1 + wave; i < m; i += (nthr >> 6)) {
+        const int ti = vg_tri(i);
+        const double di = Dc[i];
+        for (int j = lane; j < i; j += 64) {
+            const double g = Wc[ti + j];
+            double e = 0.0;
+            sG += g * g;
+            if (fabs(g) > thr) {
+                e = g / (di - Dc[j]);
+                sE += e * e;
+                mE = fmax(mE, fabs(e));
+            }
+            __hip_atomic_store(&E[i * m + j], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sE += __shfl_xor(sE, off); sG += __shfl_xor(sG, off); mE = fmax(mE, __shfl_xor(mE, off));
+    }
+    if (lane == 0) { rs[wave] = sE; rs[16 + wave] = sG; rs[32 + wave] = mE; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    sE = sG = mE = 0.0;
+    for (int w = 0; w < (nthr >> 6); ++w) { sE += rs[w]; sG += rs[16 + w]; mE = fmax(mE, rs[32 + w]); }
+    const double budget = (double)m * thr;
+    return mE <= VG_POLISH_EMAX && 4.0 * sE * sG <= budget * budget;      // NaN / inf (equal diagonals) fail both
+}
+
 // returns the buffer that holds G (packed, identity layout, diagonal included) when the phase ends; converged is set
 // when a whole sweep rotated nothing.  Wa must already hold the packed lower triangle.
 __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, double2* cs, double* Dd, int* nact_s, double thr,
@@ -208,6 +241,20 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
             dpw = vg_fshift(dpos, n1); dqw = vg_fshift(dqos, n1);           // ... and one round later
             wE = vg_sym(dpw, dqw);
         }
+    }
+    // the start basis came out of vg_refine_launch: the matrix may already be within the polish bound
+    if (J.polish && J.polish0) {
+        double* Dt = Dd + 576;
+        for (int i = tid; i < m; i += nthr) Dt[i] = Wa[vg_tri(i) + i];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (vg_polish_scan(J, Wa, Dt, thr, Dd + 520)) {
+            polished = true;
+            converged = true;
+            if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            return Wa;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     double2* cs0 = cs;            // rotations of even rounds
     double2* cs1 = cs + 256;      // ... of odd rounds
@@ -323,33 +370,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
         if (J.polish && rotations >= switch_below && Dd[512] == 0.0) {
             const double* Wc = (R & 1) ? Wb : Wa;           // off-diagonals of the current matrix, identity layout
             const double* Dc = (R & 1) ? D1 : D0;           // its diagonal
-            double sE = 0.0, sG = 0.0, mE = 0.0;
-            double* E = J.gwork;                            // strict lower triangle only, row-major, stored speculatively
-            for (int i = 1 + wave; i < m; i += (nthr >> 6)) {
-                const int ti = vg_tri(i);
-                const double di = Dc[i];
-                for (int j = lane; j < i; j += 64) {
-                    const double g = Wc[ti + j];
-                    double e = 0.0;
-                    sG += g * g;
-                    if (fabs(g) > thr) {
-                        e = g / (di - Dc[j]);
-                        sE += e * e;
-                        mE = fmax(mE, fabs(e));
-                    }
-                    __hip_atomic_store(&E[i * m + j], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                sE += __shfl_xor(sE, off); sG += __shfl_xor(sG, off); mE = fmax(mE, __shfl_xor(mE, off));
-            }
-            double* rs = Dd + 520;
-            if (lane == 0) { rs[wave] = sE; rs[16 + wave] = sG; rs[32 + wave] = mE; }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            sE = sG = mE = 0.0;
-            for (int w = 0; w < (nthr >> 6); ++w) { sE += rs[w]; sG += rs[16 + w]; mE = fmax(mE, rs[32 + w]); }
-            const double budget = (double)m * thr;
-            if (mE <= VG_POLISH_EMAX && 4.0 * sE * sG <= budget * budget) {      // NaN / inf (equal diagonals) fail both
+            if (vg_polish_scan(J, Wc, Dc, thr, Dd + 520)) {
                 polished = true;
                 converged = true;
                 break;
@@ -1285,6 +1306,56 @@ size_t vg_eigh_log_bytes(int m) {
     const size_t nb = 2 * ((m + 31) / 32), np = nb / 2;
     const size_t blk = (size_t)VG_BJ_MAXSWEEP * (nb - 1) * np * 1024 * sizeof(double);
     return blk > scalar ? blk : scalar;
+}
+
+struct VgRefineArgs { VgRefineJob job[2]; };
+__global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
+    __shared__ double red[16];
+    __shared__ double dg[256];
+    const VgRefineJob& J = a.job[blockIdx.x];
+    const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double ss = 0.0;
+    for (int idx = tid; idx < m * m; idx += 1024) { const double g = J.Gw[idx]; ss += g * g; }
+    for (int i = tid; i < m; i += 1024) dg[i] = J.Gw[i * m + i];
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    double fro = 0.0;
+    for (int w = 0; w < 16; ++w) fro += red[w];
+    const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
+    __syncthreads();
+    double mE = 0.0;
+    for (int idx = tid; idx < m * m; idx += 1024) {
+        const int i = idx / m, j = idx - i * m;
+        const double g = J.Gw[idx];
+        if (i != j && fabs(g) > thr) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
+    }
+    for (int off = 32; off > 0; off >>= 1) mE = fmax(mE, __shfl_xor(mE, off));
+    if (lane == 0) red[wave] = mE;
+    __syncthreads();
+    mE = 0.0;
+    for (int w = 0; w < 16; ++w) mE = fmax(mE, red[w]);
+    const bool ok = mE <= VG_POLISH_EMAX;                   // false also for NaN / inf
+    for (int idx = tid; idx < m * m; idx += 1024) {
+        const int i = idx / m, j = idx - i * m;
+        // the lower-triangle value decides for both (i, j) and (j, i): E is exactly skew
+        const double g = J.Gw[i >= j ? idx : j * m + i];
+        double e = 0.0;
+        if (ok && i != j && fabs(g) > thr) e = (i > j ? g : -g) / (dg[i > j ? i : j] - dg[i > j ? j : i]);
+        J.E[idx] = e;
+        J.R1[idx] = (i == j ? 1.0 : 0.0) + e;
+    }
+}
+
+hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st) {
+    if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
+    VgRefineArgs a;
+    for (int j = 0; j < njobs; ++j) {
+        a.job[j] = jobs[j];
+        if (jobs[j].m < 1 || jobs[j].m > 256) return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs), dim3(1024), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t vg_eigh_setup() {
