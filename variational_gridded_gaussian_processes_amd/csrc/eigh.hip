@@ -1314,8 +1314,10 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
     __shared__ double dg[256];
     const VgRefineJob& J = a.job[blockIdx.x];
     const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // a wave takes whole rows (coalesced, no integer division); m <= 256: at most 4 column chunks and 16 rows per wave
     double ss = 0.0;
-    for (int idx = tid; idx < m * m; idx += 1024) { const double g = J.Gw[idx]; ss += g * g; }
+    for (int i = wave; i < m; i += 16)
+        for (int j = lane; j < m; j += 64) { const double g = J.Gw[i * m + j]; ss += g * g; }
     for (int i = tid; i < m; i += 1024) dg[i] = J.Gw[i * m + i];
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     if (lane == 0) red[wave] = ss;
@@ -1324,27 +1326,28 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
     for (int w = 0; w < 16; ++w) fro += red[w];
     const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
     __syncthreads();
+    // E from the lower triangle (the value at (i, j), i > j, decides for (j, i) too: E is exactly skew); the transposed
+    // element is written by the same lane, so one pass computes every quotient once
     double mE = 0.0;
-    for (int idx = tid; idx < m * m; idx += 1024) {
-        const int i = idx / m, j = idx - i * m;
-        const double g = J.Gw[idx];
-        if (i != j && fabs(g) > thr) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
-    }
+    for (int i = wave; i < m; i += 16)
+        for (int j = lane; j < i; j += 64) {
+            const double g = J.Gw[i * m + j];
+            if (fabs(g) > thr) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
+        }
     for (int off = 32; off > 0; off >>= 1) mE = fmax(mE, __shfl_xor(mE, off));
     if (lane == 0) red[wave] = mE;
     __syncthreads();
     mE = 0.0;
     for (int w = 0; w < 16; ++w) mE = fmax(mE, red[w]);
     const bool ok = mE <= VG_POLISH_EMAX;                   // false also for NaN / inf
-    for (int idx = tid; idx < m * m; idx += 1024) {
-        const int i = idx / m, j = idx - i * m;
-        // the lower-triangle value decides for both (i, j) and (j, i): E is exactly skew
-        const double g = J.Gw[i >= j ? idx : j * m + i];
-        double e = 0.0;
-        if (ok && i != j && fabs(g) > thr) e = (i > j ? g : -g) / (dg[i > j ? i : j] - dg[i > j ? j : i]);
-        J.E[idx] = e;
-        J.R1[idx] = (i == j ? 1.0 : 0.0) + e;
-    }
+    for (int i = wave; i < m; i += 16)
+        for (int j = lane; j <= i; j += 64) {
+            if (j == i) { J.E[i * m + i] = 0.0; J.R1[i * m + i] = 1.0; continue; }
+            const double g = J.Gw[i * m + j];
+            const double e = (ok && fabs(g) > thr) ? g / (dg[i] - dg[j]) : 0.0;
+            J.E[i * m + j] = e;  J.R1[i * m + j] = e;
+            J.E[j * m + i] = -e; J.R1[j * m + i] = -e;
+        }
 }
 
 hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st) {
