@@ -192,6 +192,20 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
                                   int& nlog, int& sweeps, int& status, bool& converged, bool& polished) {
     const int m = J.m, m2 = m + (m & 1), half = m2 >> 1, n1 = m2 - 1;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    // the start basis came out of vg_refine_launch: the matrix may already be within the polish bound
+    if (J.polish && J.polish0) {
+        double* Dt = Dd + 576;
+        for (int i = tid; i < m; i += nthr) Dt[i] = Wa[vg_tri(i) + i];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (vg_polish_scan(J, Wa, Dt, thr, Dd + 520)) {
+            polished = true;
+            converged = true;
+            if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            return Wa;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     // ---- block ownership (constant for the whole phase) ----
     int rd[2][4], wr[2][4], sal[2], sbe[2];
     bool ok[2] = {false, false};
@@ -241,20 +255,6 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
             dpw = vg_fshift(dpos, n1); dqw = vg_fshift(dqos, n1);           // ... and one round later
             wE = vg_sym(dpw, dqw);
         }
-    }
-    // the start basis came out of vg_refine_launch: the matrix may already be within the polish bound
-    if (J.polish && J.polish0) {
-        double* Dt = Dd + 576;
-        for (int i = tid; i < m; i += nthr) Dt[i] = Wa[vg_tri(i) + i];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (vg_polish_scan(J, Wa, Dt, thr, Dd + 520)) {
-            polished = true;
-            converged = true;
-            if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            return Wa;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     double2* cs0 = cs;            // rotations of even rounds
     double2* cs1 = cs + 256;      // ... of odd rounds
@@ -470,7 +470,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
         for (int u = 0; u < VG_MAXMINE; ++u) {
             const int idx = tid + u * nthr;
             my_al[u] = my_be[u] = 0;
-            if (INLDS && idx < nblk) {
+            if (INLDS && !converged && idx < nblk) {       // (not needed when the dense phase already finished the job)
                 while (rowstart + al + 1 <= idx) { rowstart += al + 1; ++al; }
                 my_al[u] = al;
                 my_be[u] = idx - rowstart;
