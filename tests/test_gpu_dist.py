@@ -14,6 +14,9 @@ N1, N2, M1, M2 = 96, 70, 12, 9            # 70 rows over 2 ranks: 35 + 35; over 
 THETA = [0.2, 0.3, 1.0, 0.8, 0.01]
 
 
+NSTEP = 6
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -32,8 +35,8 @@ def _worker(rank, world, port, q):
         sh = ShardedStep(eng)
         yy = sh.sumsq_total(Y)
         out = []
-        for k in range(3):                       # cold step, then warm-started steps with moving hyper-parameters
-            th = np.array(THETA) * (1.0 + 0.05 * k)
+        for k in range(NSTEP):                   # cold, warm, extrapolated, then refined + polished starts (finish graph variants)
+            th = np.array(THETA) * (1.0 + 0.01 * k)
             e, g, info = sh.step(Y, yy, th)
             out.append((e, g))
         mean, var = eng.qv()
@@ -61,8 +64,8 @@ def test_sharded_step_equals_single_rank_and_oracle(engine, world):
     f1, f2 = Kr.Factor("points", "matern32", g1, x1), Kr.Factor("points", "matern32", g2, x2)
     engine.plan("matern32", "points", g1, x1, "matern32", "points", g2, x2, warm_start=True)
     Y = torch.tensor(y.reshape(N2, N1), device="cuda")
-    for k in range(3):
-        th = np.array(THETA) * (1.0 + 0.05 * k)
+    for k in range(NSTEP):
+        th = np.array(THETA) * (1.0 + 0.01 * k)
         ref = Kr.elbo_step(y.reshape(N2, N1), f1, f2, th)
         e1, g1_, _ = engine.elbo_step(Y, engine.sumsq(Y), th)
         for rank, out, _, _ in res:
