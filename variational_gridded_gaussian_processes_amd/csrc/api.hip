@@ -622,7 +622,9 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         info->status = status;
         info->polished = ((c->h_out->counters[0][3] >> 28) & 1) | (((c->h_out->counters[1][3] >> 28) & 1) << 1);
     }
-    c->refine_next = !status && ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1);
+    // refine the next start only where it can replace the last sweep: both dimensions polished after at most one sweep
+    c->refine_next = !status && ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1) &&
+                     c->h_out->counters[0][1] <= 1 && c->h_out->counters[1][1] <= 1;
     if (status) {          // the bases written by this step are not trustworthy: the next step starts cold
         c->warm_run = 0;
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
