@@ -259,7 +259,8 @@ def main():
                                    f"eigensolver warm start {'off' if args.cold else 'on'}",
                        "parallelism": f"grid rows sharded over {world} rank(s), one all-reduce of "
                                       f"{eng.payload_len} doubles per step" if world > 1 else "single GPU"},
-            "elbo_last": elbo, "jacobi": {"sweeps": info["sweeps"], "rounds": info["rounds"], "jitter": info["jitter"]},
+            "elbo_last": elbo, "jacobi": {"sweeps": info["sweeps"], "rounds": info["rounds"], "jitter": info["jitter"],
+                                           "polished": info.get("polished")},
             "roofline": roofline, "stages_us": stages_us, "kron_solve": ks,
         }
         if not args.no_cpu and world == 1:
