@@ -149,8 +149,11 @@ static void layout(vggp_ctx* c, Bump& b) {
         const long m = d.m, m2e = m + (m & 1);
         d.lam0 = b.take<double>(m);
         d.jitter = b.take<double>(2);
-        d.counters = b.take<int>(4);
+        d.counters = b.take<int>(8);
+        d.counters2 = d.counters + 4;
         d.perm = b.take<int>(m2e);
+        d.perm2 = b.take<int>(m2e);
+        d.lam_s = b.take<double>(m);
         d.status = b.take<int>(2);
     }
     c->invD = b.take<double>(m1 * m2);
@@ -214,6 +217,12 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
         d.rotlog = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
         d.roundlog = b.take<int>(d.max_rounds);
+        if (m >= 24 && m <= 128) {       // subspace start: the small problem has at most m/2 rows
+            d.gwork2 = b.take<double>(m2e * (m2e + 1));
+            d.rotlog2 = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
+            d.roundlog2 = b.take<int>(d.max_rounds);
+            d.Zs = b.take<double>(m * m); d.V1s = b.take<double>(m * m); d.Hs = b.take<double>(m * m); d.Ws = b.take<double>(m * m);
+        }
     }
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
     static const char* ste = getenv("VGGP_ST_TARGET");
@@ -254,6 +263,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     graphs_clear(c);
     c->warm_run = 0;
     c->refine_next = false;
+    c->sub_next = false; c->sub_mode = false; c->sub_r_cap[0] = c->sub_r_cap[1] = 0;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -313,7 +323,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         fj[k] = VgFactorJob{d.x, d.grid, d.AD, d.AD + (long)d.m * d.n, d.K0, d.dK0, d.n, d.m, d.kind, d.basis, k, 0.0, c->desc.flags};
         clr.ptr[clr.n] = d.status; clr.nwords[clr.n++] = 2;
         clr.ptr[clr.n] = reinterpret_cast<int*>(d.chol_scratch); clr.nwords[clr.n++] = 16;     // jitter-level flags
-        clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 4;                                  // Jacobi progress word
+        clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 8;                                  // Jacobi progress words (counters, counters2)
         cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
     }
     VG_HIP(vg_factor_build_launch(fj, 2, c->d_htheta, st, c->theta, &clr));
@@ -401,7 +411,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
 }
 
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
-                          bool from_slabs = false, bool extrap = false, bool refine = false) {
+                          bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -420,7 +430,70 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
     VgEigJob ej[2];
-    if (warm) {
+    if (warm && subspace) {
+        // ---- subspace start (numerically rank-deficient G, e.g. RBF: rank ~20 of 128).  S = d.F is the previous basis after
+        // one Newton-Schulz step (partials ran with U = I), rows sorted by decreasing eigenvalue; its r leading rows V span
+        // the previous numerical range.  One step of subspace iteration, Z = V G, removes every null-space component
+        // exactly (G annihilates them); V1 = orth(Z); Rayleigh-Ritz on H = V1 G V1^T gives the r leading eigenpairs;
+        // the other rows are the previous ones projected off span(V1) (the next step's Newton-Schulz restores their
+        // orthonormality, 1e-5 off after the projection).  Q G Q^T is then diagonal up to a handful of elements
+        // (tools/studies/subspace_rbf_study.py: 1-3 rotations left instead of ~12000), which the eigensolver finds by scan.
+        VgRowQrJob qj[2];
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.F, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // Z = V G
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const long r = d.sub_r;
+            qj[k] = VgRowQrJob{d.Zs, d.V1s, d.sub_r, d.m, d.F + r * d.m, d.E + r * d.m, (long)(d.m - r) * d.m};   // + E[r:] <- S[r:]
+        }
+        VG_HIP(vg_rowqr_launch(qj, 2, st));
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const long r = d.sub_r;
+            vg_gemm_add(&g, d.V1s, d.m, 1, G0[k], d.m, 1, d.TM, d.m, (int)r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // T = V1 G
+            vg_gemm_add(&g, d.F + r * d.m, d.m, 1, d.V1s, 1, d.m, d.TH, (int)r, (int)(d.m - r), (int)r, d.m);           // P = S[r:] V1^T
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const long r = d.sub_r;
+            vg_gemm_add(&g, d.TM, d.m, 1, d.V1s, 1, d.m, d.Hs, (int)r, (int)r, (int)r, d.m);                          // H = T V1^T
+            vg_gemm_add(&g, d.TH, r, 1, d.V1s, d.m, 1, d.E + r * d.m, d.m, (int)(d.m - r), d.m, (int)r, 1, 0, 1, 0, -1.0, 1);   // E[r:] -= P V1
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        VgEigJob sj[2];
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            sj[k] = VgEigJob{d.Hs, d.lam_s, d.Ws, nullptr, d.gwork2, d.rotlog2, d.roundlog2, d.counters2, d.sub_r, d.max_rounds,
+                             (long)vg_eigh_log_bytes(d.m), 0};
+            sj[k].perm = d.perm2;
+        }
+        VG_HIP(vg_eigh_launch(sj, 2, st));                                                                           // Ritz pairs
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.Ws, d.sub_r, 1, d.V1s, d.m, 1, d.E, d.m, d.sub_r, d.m, d.sub_r);                        // E[:r] = W V1
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.E, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.TM, d.m, 1, d.E, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+    } else if (warm) {
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
@@ -474,13 +547,14 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     VG_MARK(7);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? (refine ? d.E : (extrap ? d.F : d.QtPrev)) : nullptr, d.gwork, d.rotlog, d.roundlog,
+        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? ((refine || subspace) ? d.E : (extrap ? d.F : d.QtPrev)) : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
                          (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
         ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
         ej[k].perm = d.perm;
         ej[k].cp_src = d.QtPrev; ej[k].cp_dst = d.QtPrev2;      // the basis before last, for the next extrapolation
         ej[k].polish0 = (warm && refine) ? 1 : 0;
+        ej[k].sparse_first = (warm && subspace) ? 1 : 0;
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
     VG_MARK(8);
@@ -528,7 +602,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
     vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
     vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
-    if (warm && c->desc.warm_start)      // U = Q(t) Q(t-1)^T for the NEXT step's extrapolated start (both bases are final here)
+    if (warm && c->desc.warm_start && !c->sub_mode)   // U = Q(t) Q(t-1)^T for the NEXT step's extrapolated start (both bases are final here)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.U, d.m, d.m, d.m, d.m);
@@ -546,7 +620,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // ---- HIP-graph cache: the launch sequence of a step is fixed for a plan, so it is captured once per
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
-       VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_COUNT };
+       VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_COUNT };
+// _S: subspace start (see finish_enqueue)
 // _X: warm start from the extrapolated basis; _XR: ... refined to first order before the eigensolver (see finish_enqueue)
 
 static void graphs_clear(vggp_ctx* c) {
@@ -588,6 +663,24 @@ static bool vg_extrapolate(const vggp_ctx* c) {
            c->d[0].have_prev2 && c->d[1].have_prev2;
 }
 
+// start-basis strategy of this step; switching the subspace mode on puts the identity into U (the partials then run a plain
+// Newton-Schulz clean-up of QtPrev through the extrapolation products) and drops stale _S graphs when the ranks moved
+struct VgStart { bool extrap, refine, subspace; };
+static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out) {
+    out->extrap = vg_extrapolate(c);
+    out->subspace = warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0;
+    out->refine = warm && !out->subspace && vg_refine(c, out->extrap);
+    if (out->subspace && !c->sub_mode)
+        for (int k = 0; k < 2; ++k) VG_HIP(vg_identity_launch(c->d[k].U, c->d[k].m, st));
+    c->sub_mode = out->subspace;
+    if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
+        for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S})
+            if (c->gexec[v]) { (void)hipGraphExecDestroy(c->gexec[v]); c->gexec[v] = nullptr; c->gkey[v] = VgGraphKey(); }
+        c->sub_r_cap[0] = c->d[0].sub_r; c->sub_r_cap[1] = c->d[1].sub_r;
+    }
+    return VGGP_OK;
+}
+
 static int set_theta(vggp_ctx* c, const double theta[5]) {
     for (int i = 0; i < 5; ++i) {
         VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
@@ -617,14 +710,33 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     }
     if (info) {
         info->jitter1 = c->h_out->jitter[0]; info->jitter2 = c->h_out->jitter[1];
-        info->sweeps1 = c->h_out->counters[0][1]; info->sweeps2 = c->h_out->counters[1][1];
+        info->sweeps1 = c->h_out->counters[0][1] & 0xff; info->sweeps2 = c->h_out->counters[1][1] & 0xff;
         info->rounds1 = c->h_out->counters[0][0]; info->rounds2 = c->h_out->counters[1][0];
         info->status = status;
         info->polished = ((c->h_out->counters[0][3] >> 28) & 1) | (((c->h_out->counters[1][3] >> 28) & 1) << 1);
     }
+    // numerical ranks -> subspace start for the next step (rank-deficient Gram matrices only; hysteresis keeps the graph stable)
+    {
+        static const bool off = getenv("VGGP_NO_SUBSPACE") != nullptr;
+        bool ok = !status && !off && c->desc.warm_start && !(c->desc.flags & VGGP_FLAG_BLOCK_JACOBI);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const int rank = (c->h_out->counters[k][1] >> 8) & 0x1ff;
+            int want = 0;
+            if (d.Zs && rank >= 1 && 3 * rank <= d.m) {
+                want = ((rank + 4 + 7) / 8) * 8;
+                if (want < 16) want = 16;
+                if (want > 64 || 2 * want > d.m) want = 0;
+            }
+            if (want == 0) d.sub_r = 0;
+            else if (want > d.sub_r || want < d.sub_r - 8) d.sub_r = want;
+            ok = ok && d.sub_r > 0;
+        }
+        c->sub_next = ok;
+    }
     // refine the next start only where it can replace the last sweep: both dimensions polished after at most one sweep
     c->refine_next = !status && ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1) &&
-                     c->h_out->counters[0][1] <= 1 && c->h_out->counters[1][1] <= 1;
+                     (c->h_out->counters[0][1] & 0xff) <= 1 && (c->h_out->counters[1][1] & 0xff) <= 1;
     if (status) {          // the bases written by this step are not trustworthy: the next step starts cold
         c->warm_run = 0;
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
@@ -653,7 +765,9 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     if (rc) return rc;
     if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
     const VgGraphKey key{Y, payload, 0.0};
-    const bool extrap = vg_extrapolate(c);
+    VgStart sp;
+    if ((rc = vg_start_prepare(c, c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev, st, &sp))) return rc;
+    const bool extrap = sp.extrap;
     rc = run_graph(c, extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, key, st,
                    [&] { return vg_partials_enqueue(c, Y, payload, st, true, extrap); });
     if (rc) return rc;
@@ -671,10 +785,12 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     if (rc) return rc;
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{nullptr, payload, yy_total};
-    const bool extrap = vg_extrapolate(c);       // same state as at the matching vggp_elbo_partials call
-    const bool refine = warm && vg_refine(c, extrap);
-    rc = run_graph(c, warm ? (extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM) : VG_G_FINISH_COLD, key, st,
-                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap, refine); });
+    VgStart sp;                                   // same state as at the matching vggp_elbo_partials call
+    if ((rc = vg_start_prepare(c, warm, st, &sp))) return rc;
+    const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
+    rc = run_graph(c, warm ? (subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
+                            : VG_G_FINISH_COLD, key, st,
+                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap, refine, subspace); });
     if (rc) return rc;
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
@@ -690,11 +806,13 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{Y, c->payload, yy_total};
-    const bool extrap = vg_extrapolate(c);
-    const bool refine = warm && vg_refine(c, extrap);
-    rc = run_graph(c, warm ? (extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM) : VG_G_STEP_COLD, key, st, [&] {
+    VgStart sp;
+    if ((rc = vg_start_prepare(c, warm, st, &sp))) return rc;
+    const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
+    rc = run_graph(c, warm ? (subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
+                            : VG_G_STEP_COLD, key, st, [&] {
         const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace);
     });
     if (rc) return rc;
     c->have_partials = true;
@@ -987,7 +1105,7 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     int hc[4] = {0, 0, 0, 0};
     VG_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
     VG_HIP(hipStreamSynchronize(st));
-    if (sweeps_out) *sweeps_out = hc[1];
+    if (sweeps_out) *sweeps_out = hc[1] & 0xff;
     if (hc[2]) { vg_set_error("vggp_eigh: no convergence"); return VGGP_ENOCONV; }
     return VGGP_OK;
 }

@@ -131,7 +131,14 @@ struct VgEigJob {
     int fast_switch = 112; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
     int polish = 1;        // dense phase: replace the remaining sweeps by a first-order polish when its a-priori bound allows
     int polish0 = 0;       // also try the polish before the first sweep (the start basis was refined by vg_refine_launch)
+    int sparse_first = 0;  // skip the dense phase: the start basis already block-diagonalises G (subspace start), a few elements remain
 };
+#define VG_EIG_RANK_CUT 1e-14   // eigenvalues above this fraction of the largest count towards the numerical rank (counters[1] >> 8)
+// Row orthonormalisation for the subspace start (eigh.hip): V1 = rows of Z (r x m, r <= 64, m <= 128) orthonormalised in the
+// given order (classical Gram-Schmidt, re-orthogonalised), one workgroup per job; also copies cp_src -> cp_dst (cp_n doubles).
+struct VgRowQrJob { const double* Z; double* V1; int r; int m; const double* cp_src; double* cp_dst; long cp_n; };
+hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_identity_launch(double* A, int m, hipStream_t st);
 // First-order refinement of a warm start (eigh.hip): from Gw = S G S^T, E_ij = g_ij / (g_ii - g_jj) for the elements above
 // the eigensolver's threshold; outputs E and R1 = I + E (both [m][m]); E = 0, R1 = I when some |E_ij| > 1e-3.
 struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol; };

@@ -13,6 +13,11 @@ struct VgDim {
     double2* rotlog = nullptr;
     int *roundlog = nullptr, *counters = nullptr, *status = nullptr, *perm = nullptr;
     int gh_split = 1, max_rounds = 0;
+    // subspace start (numerically rank-deficient Gram matrices, e.g. RBF): scratch for the r leading rows and the small eigenproblem
+    double *Zs = nullptr, *V1s = nullptr, *Hs = nullptr, *Ws = nullptr, *lam_s = nullptr, *gwork2 = nullptr;
+    double2* rotlog2 = nullptr;
+    int *roundlog2 = nullptr, *counters2 = nullptr, *perm2 = nullptr;
+    int sub_r = 0;                    // rows treated as the numerical range in the next step (0: subspace start off)
     bool have_prev = false, have_prev2 = false;     // QtPrev / QtPrev2 hold the bases of the last / the step before
 };
 
@@ -60,7 +65,10 @@ struct vggp_ctx {
     bool use_graph = true;
     hipGraphExec_t gexec[12] = {};
     VgGraphKey gkey[12];
-    bool refine_next = false;         // the last step ended in the polish in both dimensions: refine the next start basis
+    bool refine_next = false;
+    bool sub_next = false;            // the last step's numerical ranks allow the subspace start
+    int sub_r_cap[2] = {0, 0};        // ranks the _S graphs were captured with
+    bool sub_mode = false;            // U holds the identity (plain Newton-Schulz clean-up of QtPrev instead of the extrapolation)         // the last step ended in the polish in both dimensions: refine the next start basis
     int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
     bool prof = false;

@@ -455,7 +455,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     int nlog = 0, sweeps = 0, status = 0;
     bool converged = false, polished = false;
     RT(1);
-    if (INLDS && fast)           // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
+    if (INLDS && fast && !J.sparse_first)   // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
         W = vg_jacobi_fast(J, W, W + ((m2 * (m2 + 1)) >> 1), cs, reinterpret_cast<double*>(pq), nact_s, thr, nlog, sweeps,
                            status, converged, polished);
 
@@ -635,8 +635,12 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ranks are at the L2 before DONE is published
     __syncthreads();
     if (tid == 0) {
+        double lmax = 0.0;
+        for (int j = 0; j < m; ++j) lmax = fmax(lmax, dg[j]);
+        int nrank = 0;
+        for (int j = 0; j < m; ++j) nrank += dg[j] > VG_EIG_RANK_CUT * lmax ? 1 : 0;
         J.counters[0] = nlog;
-        J.counters[1] = sweeps;
+        J.counters[1] = sweeps | (nrank << 8);               // numerical rank rides above the sweep count
         J.counters[2] = status;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE | (polished ? VG_EIG_POLISH : 0), __ATOMIC_RELAXED,
@@ -1308,6 +1312,83 @@ size_t vg_eigh_log_bytes(int m) {
     return blk > scalar ? blk : scalar;
 }
 
+// ---- row orthonormalisation (subspace start) --------------------------------------------------------------------------
+// The rows of Z = V G are dominated by what leaks onto the leading eigenvectors (row k is lambda_k v_k + sum_j phi_kj lambda_j u_j
+// with phi ~ 1e-3), so their Gram matrix is numerically singular and Cholesky-QR is out; the deflation has to run top-down.
+// Classical Gram-Schmidt with re-orthogonalisation, row by row, everything in LDS: the k dot products of a row are taken
+// by the 16 waves in parallel, then 128 lanes subtract; a third pass when a pass removed most of the row.
+struct VgRowQrArgs { VgRowQrJob job[2]; };
+__global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
+    __shared__ double cj[64];
+    __shared__ double nrm[2];
+    const VgRowQrJob& J = a.job[blockIdx.x];
+    const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* V = vq_dyn;                 // [r][m] finished rows
+    double* v = vq_dyn + r * m;         // [m] the row in work
+    for (long i = tid; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];
+    for (int k = 0; k < r; ++k) {
+        for (int e = tid; e < m; e += 1024) v[e] = J.Z[(long)k * m + e];
+        __syncthreads();
+        for (int pass = 0; pass < 3; ++pass) {
+            // c_j = V_j . v for j < k (wave per j), and |v|^2 (wave 15 takes it when free, else wave 0 afterwards)
+            for (int j = wave; j < k; j += 16) {
+                double s = 0.0;
+                for (int e = lane; e < m; e += 64) s += V[j * m + e] * v[e];
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) cj[j] = s;
+            }
+            if (wave == 15) {
+                double s = 0.0;
+                for (int e = lane; e < m; e += 64) s += v[e] * v[e];
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) nrm[0] = s;
+            }
+            __syncthreads();
+            if (tid < m) {
+                double x = v[tid];
+                for (int j = 0; j < k; ++j) x -= cj[j] * V[j * m + tid];
+                v[tid] = x;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                double s = 0.0;
+                for (int e = lane; e < m; e += 64) s += v[e] * v[e];
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) nrm[1] = s;
+            }
+            __syncthreads();
+            if (pass >= 1 && nrm[1] > 0.25 * nrm[0]) break;       // uniform: the last pass removed little -> orthogonal enough
+        }
+        const double sc = nrm[1] > 0.0 ? 1.0 / sqrt(nrm[1]) : 0.0;
+        if (tid < m) { const double x = v[tid] * sc; V[k * m + tid] = x; J.V1[(long)k * m + tid] = x; }
+        __syncthreads();
+    }
+}
+
+hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st) {
+    if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
+    VgRowQrArgs a;
+    size_t lds = 0;
+    for (int j = 0; j < njobs; ++j) {
+        a.job[j] = jobs[j];
+        if (jobs[j].r < 1 || jobs[j].r > 64 || jobs[j].m < jobs[j].r || jobs[j].m > 128) return hipErrorInvalidValue;
+        const size_t need = ((size_t)jobs[j].r + 1) * jobs[j].m * sizeof(double);
+        if (need > lds) lds = need;
+    }
+    hipLaunchKernelGGL(vg_rowqr_kernel, dim3(njobs), dim3(1024), lds, st, a);
+    return hipGetLastError();
+}
+
+__global__ void vg_identity_kernel(double* A, int m) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < m * m) A[idx] = (idx / m == idx % m) ? 1.0 : 0.0;
+}
+hipError_t vg_identity_launch(double* A, int m, hipStream_t st) {
+    hipLaunchKernelGGL(vg_identity_kernel, dim3((m * m + 255) / 256), dim3(256), 0, st, A, m);
+    return hipGetLastError();
+}
+
 struct VgRefineArgs { VgRefineJob job[2]; };
 __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
     __shared__ double red[16];
@@ -1362,6 +1443,9 @@ hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st) 
 }
 
 hipError_t vg_eigh_setup() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_rowqr_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
 }
