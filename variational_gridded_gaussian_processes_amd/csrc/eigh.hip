@@ -1320,18 +1320,19 @@ size_t vg_eigh_log_bytes(int m) {
 struct VgRowQrArgs { VgRowQrJob job[2]; };
 __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
-    __shared__ double cj[64];
-    __shared__ double nrm[2];
+    __shared__ double cj[72];
+    __shared__ double nrm[4];
     const VgRowQrJob& J = a.job[blockIdx.x];
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* V = vq_dyn;                 // [r][m] finished rows
-    double* v = vq_dyn + r * m;         // [m] the row in work
+    double* V = vq_dyn;                 // [r][m]: rows < k are finished, row k is in work, rows > k still hold Z (one load)
+    for (int i = tid; i < r * m; i += 1024) V[i] = J.Z[i];
     for (long i = tid; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];
+    __syncthreads();
     for (int k = 0; k < r; ++k) {
-        for (int e = tid; e < m; e += 1024) v[e] = J.Z[(long)k * m + e];
-        __syncthreads();
-        for (int pass = 0; pass < 3; ++pass) {
-            // c_j = V_j . v for j < k (wave per j), and |v|^2 (wave 15 takes it when free, else wave 0 afterwards)
+        double* v = V + k * m;
+        double prev = 0.0, now = 0.0;
+        for (int pass = 0;; ++pass) {
+            // c_j = V_j . v for j < k (a wave per j) and |v|^2 (last wave)
             for (int j = wave; j < k; j += 16) {
                 double s = 0.0;
                 for (int e = lane; e < m; e += 64) s += V[j * m + e] * v[e];
@@ -1342,26 +1343,30 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
                 double s = 0.0;
                 for (int e = lane; e < m; e += 64) s += v[e] * v[e];
                 for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                if (lane == 0) nrm[0] = s;
+                if (lane == 0) nrm[pass & 1] = s;
             }
             __syncthreads();
+            now = nrm[pass & 1];
+            // re-orthogonalised twice; a further pass only while the last one still removed most of the row
+            if (pass >= 2 && now > 0.25 * prev) break;
+            if (pass >= 5) break;
+            prev = now;
             if (tid < m) {
-                double x = v[tid];
-                for (int j = 0; j < k; ++j) x -= cj[j] * V[j * m + tid];
-                v[tid] = x;
+                double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+                int j = 0;
+                for (; j + 3 < k; j += 4) {               // independent partial sums: the LDS loads pipeline
+                    x0 += cj[j] * V[j * m + tid];
+                    x1 += cj[j + 1] * V[(j + 1) * m + tid];
+                    x2 += cj[j + 2] * V[(j + 2) * m + tid];
+                    x3 += cj[j + 3] * V[(j + 3) * m + tid];
+                }
+                for (; j < k; ++j) x0 += cj[j] * V[j * m + tid];
+                v[tid] -= (x0 + x1) + (x2 + x3);
             }
             __syncthreads();
-            if (wave == 0) {
-                double s = 0.0;
-                for (int e = lane; e < m; e += 64) s += v[e] * v[e];
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                if (lane == 0) nrm[1] = s;
-            }
-            __syncthreads();
-            if (pass >= 1 && nrm[1] > 0.25 * nrm[0]) break;       // uniform: the last pass removed little -> orthogonal enough
         }
-        const double sc = nrm[1] > 0.0 ? 1.0 / sqrt(nrm[1]) : 0.0;
-        if (tid < m) { const double x = v[tid] * sc; V[k * m + tid] = x; J.V1[(long)k * m + tid] = x; }
+        const double sc = now > 0.0 ? 1.0 / sqrt(now) : 0.0;
+        if (tid < m) { const double x = v[tid] * sc; v[tid] = x; J.V1[(long)k * m + tid] = x; }
         __syncthreads();
     }
 }
@@ -1373,7 +1378,7 @@ hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st) {
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         if (jobs[j].r < 1 || jobs[j].r > 64 || jobs[j].m < jobs[j].r || jobs[j].m > 128) return hipErrorInvalidValue;
-        const size_t need = ((size_t)jobs[j].r + 1) * jobs[j].m * sizeof(double);
+        const size_t need = (size_t)jobs[j].r * jobs[j].m * sizeof(double);
         if (need > lds) lds = need;
     }
     hipLaunchKernelGGL(vg_rowqr_kernel, dim3(njobs), dim3(1024), lds, st, a);
