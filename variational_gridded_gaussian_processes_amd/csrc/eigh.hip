@@ -1325,8 +1325,12 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     const VgRowQrJob& J = a.job[blockIdx.x];
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* V = vq_dyn;                 // [r][m]: rows < k are finished, row k is in work, rows > k still hold Z (one load)
+    // the pass-through copy: loads now (registers), stores after the last row -- a global store inside the row loop would be
+    // waited for at every barrier (__syncthreads drains vmcnt)
+    double cpv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; cpv[u] = i < J.cp_n ? J.cp_src[i] : 0.0; }
     for (int i = tid; i < r * m; i += 1024) V[i] = J.Z[i];
-    for (long i = tid; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];
     __syncthreads();
     for (int k = 0; k < r; ++k) {
         double* v = V + k * m;
@@ -1366,9 +1370,13 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
             __syncthreads();
         }
         const double sc = now > 0.0 ? 1.0 / sqrt(now) : 0.0;
-        if (tid < m) { const double x = v[tid] * sc; v[tid] = x; J.V1[(long)k * m + tid] = x; }
+        if (tid < m) v[tid] *= sc;
         __syncthreads();
     }
+    for (int i = tid; i < r * m; i += 1024) J.V1[i] = V[i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; if (i < J.cp_n) J.cp_dst[i] = cpv[u]; }
+    for (long i = tid + 16 * 1024L; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];      // (m <= 128: never taken)
 }
 
 hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st) {
