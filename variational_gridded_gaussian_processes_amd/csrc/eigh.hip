@@ -1321,7 +1321,6 @@ struct VgRowQrArgs { VgRowQrJob job[2]; };
 __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
     __shared__ double cj[72];
-    __shared__ double nrm[4];
     const VgRowQrJob& J = a.job[blockIdx.x];
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* V = vq_dyn;                 // [r][m]: rows < k are finished, row k is in work, rows > k still hold Z (one load)
@@ -1332,29 +1331,17 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; cpv[u] = i < J.cp_n ? J.cp_src[i] : 0.0; }
     for (int i = tid; i < r * m; i += 1024) V[i] = J.Z[i];
     __syncthreads();
+    const int grp = lane >> 4, l16 = lane & 15, jmine = wave * 4 + grp;       // 16 lanes per previous row: 64 rows in one go
     for (int k = 0; k < r; ++k) {
         double* v = V + k * m;
-        double prev = 0.0, now = 0.0;
-        for (int pass = 0;; ++pass) {
-            // c_j = V_j . v for j < k (a wave per j) and |v|^2 (last wave)
-            for (int j = wave; j < k; j += 16) {
+        for (int pass = 0; pass < 2; ++pass) {                 // classical Gram-Schmidt, twice
+            if (jmine < k) {
                 double s = 0.0;
-                for (int e = lane; e < m; e += 64) s += V[j * m + e] * v[e];
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                if (lane == 0) cj[j] = s;
-            }
-            if (wave == 15) {
-                double s = 0.0;
-                for (int e = lane; e < m; e += 64) s += v[e] * v[e];
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                if (lane == 0) nrm[pass & 1] = s;
+                for (int e = l16; e < m; e += 16) s += V[jmine * m + e] * v[e];
+                s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+                if (l16 == 0) cj[jmine] = s;
             }
             __syncthreads();
-            now = nrm[pass & 1];
-            // re-orthogonalised twice; a further pass only while the last one still removed most of the row
-            if (pass >= 2 && now > 0.25 * prev) break;
-            if (pass >= 5) break;
-            prev = now;
             if (tid < m) {
                 double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
                 int j = 0;
@@ -1369,8 +1356,15 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
             }
             __syncthreads();
         }
-        const double sc = now > 0.0 ? 1.0 / sqrt(now) : 0.0;
-        if (tid < m) v[tid] *= sc;
+        if (tid < 128) {                                       // the (at most two) waves that own elements normalise them
+            double s = 0.0;
+            for (int e = lane; e < m; e += 64) s += v[e] * v[e];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            const double sc = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+            double x = tid < m ? v[tid] * sc : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            if (tid < m) v[tid] = x;
+        }
         __syncthreads();
     }
     for (int i = tid; i < r * m; i += 1024) J.V1[i] = V[i];
