@@ -361,6 +361,8 @@ def test_polish_ends_warm_matern_steps(engine):
             assert rel(elbo, st.elbo) < RTOL and rel(grad, st.grad) < 1e-6, (kind, t)
             hits += int(all(info["polished"]))
         assert (hits >= 3) == expect, (kind, hits)
+        if kind == "rbf":        # rank-deficient Gram matrices: the subspace start leaves the eigensolver a handful of rounds
+            assert sum(info["rounds"]) < 60, info
 
 
 def test_polish_odd_m_vff_trajectory(engine):
