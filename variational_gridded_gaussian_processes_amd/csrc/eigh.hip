@@ -1320,7 +1320,6 @@ size_t vg_eigh_log_bytes(int m) {
 struct VgRowQrArgs { VgRowQrJob job[2]; };
 __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
-    __shared__ double cj[72];
     const VgRowQrJob& J = a.job[blockIdx.x];
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* V = vq_dyn;                 // [r][m]: rows < k are finished, row k is in work, rows > k still hold Z (one load)
@@ -1331,39 +1330,69 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; cpv[u] = i < J.cp_n ? J.cp_src[i] : 0.0; }
     for (int i = tid; i < r * m; i += 1024) V[i] = J.Z[i];
     __syncthreads();
-    const int grp = lane >> 4, l16 = lane & 15, jmine = wave * 4 + grp;       // 16 lanes per previous row: 64 rows in one go
-    for (int k = 0; k < r; ++k) {
-        double* v = V + k * m;
-        for (int pass = 0; pass < 2; ++pass) {                 // classical Gram-Schmidt, twice
-            if (jmine < k) {
+    // Block Gram-Schmidt, 4 rows at a time (r is a multiple of 4): the block is projected off all finished rows twice
+    // (4 k0 dot products per pass, 16 lanes each, one barrier; 512 threads subtract), then wave 0 alone orthonormalises the
+    // four rows among themselves in registers (two elements per lane, wave reductions, no workgroup barrier).
+    __shared__ double cb[4 * 64];
+    const int grp = tid >> 4, l16 = lane & 15;               // 64 groups of 16 lanes
+    for (int k0 = 0; k0 < r; k0 += 4) {
+        double* vb = V + k0 * m;
+        for (int pass = 0; pass < 2 && k0 > 0; ++pass) {
+            for (int p = grp; p < 4 * k0; p += 64) {
+                const int bb = p & 3, j = p >> 2;
                 double s = 0.0;
-                for (int e = l16; e < m; e += 16) s += V[jmine * m + e] * v[e];
+                for (int e = l16; e < m; e += 16) s += V[j * m + e] * vb[bb * m + e];
                 s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-                if (l16 == 0) cj[jmine] = s;
+                if (l16 == 0) cb[bb * 64 + j] = s;
             }
             __syncthreads();
-            if (tid < m) {
-                double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-                int j = 0;
-                for (; j + 3 < k; j += 4) {               // independent partial sums: the LDS loads pipeline
-                    x0 += cj[j] * V[j * m + tid];
-                    x1 += cj[j + 1] * V[(j + 1) * m + tid];
-                    x2 += cj[j + 2] * V[(j + 2) * m + tid];
-                    x3 += cj[j + 3] * V[(j + 3) * m + tid];
+            if (tid < 512) {
+                const int e = tid & 127, bb = tid >> 7;
+                if (e < m) {
+                    const double* cc = cb + bb * 64;
+                    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+                    int j = 0;
+                    for (; j + 3 < k0; j += 4) {
+                        x0 += cc[j] * V[j * m + e];
+                        x1 += cc[j + 1] * V[(j + 1) * m + e];
+                        x2 += cc[j + 2] * V[(j + 2) * m + e];
+                        x3 += cc[j + 3] * V[(j + 3) * m + e];
+                    }
+                    for (; j < k0; ++j) x0 += cc[j] * V[j * m + e];
+                    vb[bb * m + e] -= (x0 + x1) + (x2 + x3);
                 }
-                for (; j < k; ++j) x0 += cj[j] * V[j * m + tid];
-                v[tid] -= (x0 + x1) + (x2 + x3);
             }
             __syncthreads();
         }
-        if (tid < 128) {                                       // the (at most two) waves that own elements normalise them
-            double s = 0.0;
-            for (int e = lane; e < m; e += 64) s += v[e] * v[e];
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            const double sc = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
-            double x = tid < m ? v[tid] * sc : 0.0;
-            __builtin_amdgcn_wave_barrier();
-            if (tid < m) v[tid] = x;
+        if (wave == 0) {
+            double x[4][2];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                x[bb][0] = lane < m ? vb[bb * m + lane] : 0.0;
+                x[bb][1] = lane + 64 < m ? vb[bb * m + lane + 64] : 0.0;
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                    for (int jb = 0; jb < bb; ++jb) {
+                        double c = x[bb][0] * x[jb][0] + x[bb][1] * x[jb][1];
+                        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+                        x[bb][0] -= c * x[jb][0];
+                        x[bb][1] -= c * x[jb][1];
+                    }
+                }
+                double n2 = x[bb][0] * x[bb][0] + x[bb][1] * x[bb][1];
+                for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
+                const double sc = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+                x[bb][0] *= sc; x[bb][1] *= sc;
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if (lane < m) vb[bb * m + lane] = x[bb][0];
+                if (lane + 64 < m) vb[bb * m + lane + 64] = x[bb][1];
+            }
         }
         __syncthreads();
     }
