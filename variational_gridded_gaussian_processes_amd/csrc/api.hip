@@ -455,7 +455,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
-            vg_gemm_add(&g, d.V1s, d.m, 1, G0[k], d.m, 1, d.TM, d.m, (int)r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // T = V1 G
+            vg_gemm_add(&g, d.V1s, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, (int)r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // T = V1 G (Z is spent)
             vg_gemm_add(&g, d.F + r * d.m, d.m, 1, d.V1s, 1, d.m, d.TH, (int)r, (int)(d.m - r), (int)r, d.m);           // P = S[r:] V1^T
         }
         VG_HIP(vg_gemm_launch(&g, st));
@@ -463,7 +463,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
-            vg_gemm_add(&g, d.TM, d.m, 1, d.V1s, 1, d.m, d.Hs, (int)r, (int)r, (int)r, d.m);                          // H = T V1^T
+            vg_gemm_add(&g, d.Zs, d.m, 1, d.V1s, 1, d.m, d.Hs, (int)r, (int)r, (int)r, d.m);                          // H = T V1^T
             vg_gemm_add(&g, d.TH, r, 1, d.V1s, d.m, 1, d.E + r * d.m, d.m, (int)(d.m - r), d.m, (int)r, 1, 0, 1, 0, -1.0, 1);   // E[r:] -= P V1
         }
         VG_HIP(vg_gemm_launch(&g, st));
@@ -478,13 +478,11 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.Ws, d.sub_r, 1, d.V1s, d.m, 1, d.E, d.m, d.sub_r, d.m, d.sub_r);                        // E[:r] = W V1
-        }
-        VG_HIP(vg_gemm_launch(&g, st));
-        vg_gemm_init(&g);
-        for (int k = 0; k < 2; ++k) {
-            VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.E, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            const long r = d.sub_r;
+            vg_gemm_add(&g, d.Ws, r, 1, d.V1s, d.m, 1, d.E, d.m, (int)r, d.m, (int)r);                                // E[:r] = W V1
+            vg_gemm_add(&g, d.Ws, r, 1, d.Zs, d.m, 1, d.TM, d.m, (int)r, d.m, (int)r);                                 // (E G)[:r] = W T
+            vg_gemm_add(&g, d.E + r * d.m, d.m, 1, G0[k], d.m, 1, d.TM + r * d.m, d.m, (int)(d.m - r), d.m, d.m, 1, 0,
+                        ghn[k], ghs[k]);                                                                                 // (E G)[r:]
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);
