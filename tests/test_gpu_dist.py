@@ -17,7 +17,7 @@ THETA = [0.2, 0.3, 1.0, 0.8, 0.01]
 NSTEP = 6
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind="matern32", m1=M1, m2=M2):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from oracle import dense as D
@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
         X, y, x1, x2 = D.gen_grid(N1, N2)
         rows = shard_rows(N2, rank, world)
         eng = Engine(0)
-        eng.plan("matern32", "points", np.linspace(0, 1, M1), x1, "matern32", "points", np.linspace(0, 1, M2), x2[rows],
+        eng.plan(kind, "points", np.linspace(0, 1, m1), x1, kind, "points", np.linspace(0, 1, m2), x2[rows],
                  n_total=N1 * N2, warm_start=True)
         Y = torch.tensor(y.reshape(N2, N1)[rows], device="cuda:0")
         sh = ShardedStep(eng)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
         for k in range(NSTEP):                   # cold, warm, extrapolated, then refined + polished starts (finish graph variants)
             th = np.array(THETA) * (1.0 + 0.01 * k)
             e, g, info = sh.step(Y, yy, th)
-            out.append((e, g))
+            out.append((e, g, sum(info["rounds"])))
         mean, var = eng.qv()
         q.put((rank, out, mean.cpu().numpy(), var.cpu().numpy()))
         dist.barrier()
@@ -69,7 +69,7 @@ def test_sharded_step_equals_single_rank_and_oracle(engine, world):
         ref = Kr.elbo_step(y.reshape(N2, N1), f1, f2, th)
         e1, g1_, _ = engine.elbo_step(Y, engine.sumsq(Y), th)
         for rank, out, _, _ in res:
-            e, g = out[k]
+            e, g = out[k][:2]
             assert abs(e - ref.elbo) <= 1e-9 * abs(ref.elbo)
             assert np.abs(g - ref.grad).max() <= 1e-7 * np.abs(ref.grad).max()
             assert abs(e - e1) <= 1e-10 * abs(e1)
@@ -78,3 +78,31 @@ def test_sharded_step_equals_single_rank_and_oracle(engine, world):
     for _, _, mean, var in res:
         assert np.abs(mean - rm).max() <= 1e-7 * np.abs(rm).max()
         assert np.abs(var - rv).max() <= 1e-7 * np.abs(rv).max()
+
+
+def test_sharded_rbf_runs_the_subspace_start(engine):
+    """RBF factors (numerically rank-deficient Gram matrices): the split partials -> all-reduce -> finish path takes the
+    subspace start once the ranks are known (few rotation rounds) and still equals the oracle."""
+    from oracle import dense as D, kron as Kr
+    world, kind, m1, m2 = 2, "rbf", 88, 80
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, m1, m2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    X, y, x1, x2 = D.gen_grid(N1, N2)
+    f1 = Kr.Factor("points", kind, np.linspace(0, 1, m1), x1)
+    f2 = Kr.Factor("points", kind, np.linspace(0, 1, m2), x2)
+    for k in range(NSTEP):
+        th = np.array(THETA) * (1.0 + 0.01 * k)
+        ref = Kr.elbo_step(y.reshape(N2, N1), f1, f2, th)
+        for rank, out, _, _ in res:
+            e, g, rounds = out[k]
+            assert abs(e - ref.elbo) <= 1e-8 * abs(ref.elbo)
+            assert np.abs(g - ref.grad).max() <= 1e-6 * np.abs(ref.grad).max()
+    assert all(r[1][NSTEP - 1][2] < 60 for r in res), [r[1][NSTEP - 1][2] for r in res]
