@@ -410,6 +410,11 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     return VGGP_OK;
 }
 
+// The subspace start is fed the previous basis itself (U = I: the partials' extrapolation products reduce to its Newton-Schulz
+// clean-up).  VGGP_SUB_EXTRAP=1 feeds it the extrapolated basis instead: 5 us faster at m = 128, but at m = 64 the main
+// eigensolver was seen to need 55 rounds instead of ~10, so it is not the default.
+static bool vg_sub_ident() { static const bool ex = getenv("VGGP_SUB_EXTRAP") != nullptr; return !ex; }
+
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
                           bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
@@ -600,7 +605,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
     vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
     vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
-    if (warm && c->desc.warm_start && !c->sub_mode)   // U = Q(t) Q(t-1)^T for the NEXT step's extrapolated start (both bases are final here)
+    if (warm && c->desc.warm_start && !(c->sub_mode && vg_sub_ident()))   // U = Q(t) Q(t-1)^T for the NEXT step's extrapolated start (both bases are final here)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.U, d.m, d.m, d.m, d.m);
@@ -668,7 +673,7 @@ static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out
     out->extrap = vg_extrapolate(c);
     out->subspace = warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0;
     out->refine = warm && !out->subspace && vg_refine(c, out->extrap);
-    if (out->subspace && !c->sub_mode)
+    if (out->subspace && !c->sub_mode && vg_sub_ident())
         for (int k = 0; k < 2; ++k) VG_HIP(vg_identity_launch(c->d[k].U, c->d[k].m, st));
     c->sub_mode = out->subspace;
     if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
