@@ -1375,12 +1375,18 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
             for (int bb = 0; bb < 4; ++bb) {
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
+                    double c[3] = {0.0, 0.0, 0.0};             // classical order: the (up to three) reductions are independent
+#pragma unroll
+                    for (int jb = 0; jb < bb; ++jb) c[jb] = x[bb][0] * x[jb][0] + x[bb][1] * x[jb][1];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                        for (int jb = 0; jb < bb; ++jb) c[jb] += __shfl_xor(c[jb], off);
+                    }
 #pragma unroll
                     for (int jb = 0; jb < bb; ++jb) {
-                        double c = x[bb][0] * x[jb][0] + x[bb][1] * x[jb][1];
-                        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-                        x[bb][0] -= c * x[jb][0];
-                        x[bb][1] -= c * x[jb][1];
+                        x[bb][0] -= c[jb] * x[jb][0];
+                        x[bb][1] -= c[jb] * x[jb][1];
                     }
                 }
                 double n2 = x[bb][0] * x[bb][0] + x[bb][1] * x[bb][1];
