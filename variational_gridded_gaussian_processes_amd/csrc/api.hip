@@ -444,12 +444,21 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         // orthonormality, 1e-5 off after the projection).  Q G Q^T is then diagonal up to a handful of elements
         // (tools/studies/subspace_rbf_study.py: 1-3 rotations left instead of ~12000), which the eigensolver finds by scan.
         VgRowQrJob qj[2];
+        // G is read three times in this chain; in the fused step it is still split-K slabs, so the first launch also leaves a
+        // reduced copy (U holds the identity in this mode: "U G" is the slab sum) for the other two
+        const double* Gr[2] = {G0[0], G0[1]};
+        int grn[2] = {ghn[0], ghn[1]};
+        double* gdst[2] = {d1.GH, c->payload};
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, d.F, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // Z = V G
+            if (from_slabs && ghn[k] > 1 && vg_sub_ident())
+                vg_gemm_add(&g, d.U, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
         }
         VG_HIP(vg_gemm_launch(&g, st));
+        for (int k = 0; k < 2; ++k)
+            if (from_slabs && ghn[k] > 1 && vg_sub_ident()) { Gr[k] = gdst[k]; grn[k] = 1; }
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
@@ -460,7 +469,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
-            vg_gemm_add(&g, d.V1s, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, (int)r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // T = V1 G (Z is spent)
+            vg_gemm_add(&g, d.V1s, d.m, 1, Gr[k], d.m, 1, d.Zs, d.m, (int)r, d.m, d.m, 1, 0, grn[k], ghs[k]);        // T = V1 G (Z is spent)
             vg_gemm_add(&g, d.F + r * d.m, d.m, 1, d.V1s, 1, d.m, d.TH, (int)r, (int)(d.m - r), (int)r, d.m);           // P = S[r:] V1^T
         }
         VG_HIP(vg_gemm_launch(&g, st));
@@ -486,8 +495,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             const long r = d.sub_r;
             vg_gemm_add(&g, d.Ws, r, 1, d.V1s, d.m, 1, d.E, d.m, (int)r, d.m, (int)r);                                // E[:r] = W V1
             vg_gemm_add(&g, d.Ws, r, 1, d.Zs, d.m, 1, d.TM, d.m, (int)r, d.m, (int)r);                                 // (E G)[:r] = W T
-            vg_gemm_add(&g, d.E + r * d.m, d.m, 1, G0[k], d.m, 1, d.TM + r * d.m, d.m, (int)(d.m - r), d.m, d.m, 1, 0,
-                        ghn[k], ghs[k]);                                                                                 // (E G)[r:]
+            vg_gemm_add(&g, d.E + r * d.m, d.m, 1, Gr[k], d.m, 1, d.TM + r * d.m, d.m, (int)(d.m - r), d.m, d.m, 1, 0,
+                        grn[k], ghs[k]);                                                                                 // (E G)[r:]
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);
