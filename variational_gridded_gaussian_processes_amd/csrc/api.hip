@@ -181,6 +181,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.QtPrev = b.take<double>(m * m);
         d.QtPrev2 = b.take<double>(m * m);
         d.U = b.take<double>(m * m);
+        d.Id = b.take<double>(m * m);
         d.Gw = b.take<double>(m * m);
         d.GH = b.take<double>(2 * m * m);
         d.Mk = b.take<double>(m * m);
@@ -294,6 +295,8 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
             VG_HIP(hipMemcpy(d.grid, hg, sizeof(double) * glen, hipMemcpyHostToDevice));
         }
     }
+    for (int k = 0; k < 2; ++k) VG_HIP(vg_identity_launch(c->d[k].Id, c->d[k].m, nullptr));
+    VG_HIP(hipDeviceSynchronize());
     c->desc.x1 = c->desc.x2 = c->desc.grid1 = c->desc.grid2 = nullptr;   // host pointers not retained
     c->have_partials = c->have_step = c->have_masked = false;
     c->planned = true;
@@ -445,7 +448,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         // (tools/studies/subspace_rbf_study.py: 1-3 rotations left instead of ~12000), which the eigensolver finds by scan.
         VgRowQrJob qj[2];
         // G is read three times in this chain; in the fused step it is still split-K slabs, so the first launch also leaves a
-        // reduced copy (U holds the identity in this mode: "U G" is the slab sum) for the other two
+        // reduced copy ("Id G" through the slab-summing GEMM) for the other two
         const double* Gr[2] = {G0[0], G0[1]};
         int grn[2] = {ghn[0], ghn[1]};
         double* gdst[2] = {d1.GH, c->payload};
@@ -453,12 +456,12 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, d.F, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // Z = V G
-            if (from_slabs && ghn[k] > 1 && vg_sub_ident())
-                vg_gemm_add(&g, d.U, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            if (from_slabs && ghn[k] > 1)
+                vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
         }
         VG_HIP(vg_gemm_launch(&g, st));
         for (int k = 0; k < 2; ++k)
-            if (from_slabs && ghn[k] > 1 && vg_sub_ident()) { Gr[k] = gdst[k]; grn[k] = 1; }
+            if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; }
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
@@ -506,10 +509,17 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         }
         VG_HIP(vg_gemm_launch(&g, st));
     } else if (warm) {
+        const double* Gr[2] = {G0[0], G0[1]};
+        int grn[2] = {ghn[0], ghn[1]};
+        double* gdst[2] = {d1.GH, c->payload};
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, extrap ? d.F : d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            if (refine && from_slabs && ghn[k] > 1) {        // G is read again after the refinement: leave a reduced copy
+                vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                Gr[k] = gdst[k]; grn[k] = 1;
+            }
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);
@@ -545,7 +555,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_init(&g);
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
-                vg_gemm_add(&g, d.E, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                vg_gemm_add(&g, d.E, d.m, 1, Gr[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, grn[k], ghs[k]);
             }
             VG_HIP(vg_gemm_launch(&g, st));
             vg_gemm_init(&g);

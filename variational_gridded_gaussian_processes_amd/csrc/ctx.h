@@ -14,6 +14,7 @@ struct VgDim {
     int *roundlog = nullptr, *counters = nullptr, *status = nullptr, *perm = nullptr;
     int gh_split = 1, max_rounds = 0;
     // subspace start (numerically rank-deficient Gram matrices, e.g. RBF): scratch for the r leading rows and the small eigenproblem
+    double* Id = nullptr;             // m x m identity ("Id G" through the slab-summing GEMM = the reduced G)
     double *Zs = nullptr, *V1s = nullptr, *Hs = nullptr, *Ws = nullptr, *lam_s = nullptr, *gwork2 = nullptr;
     double2* rotlog2 = nullptr;
     int *roundlog2 = nullptr, *counters2 = nullptr, *perm2 = nullptr;
