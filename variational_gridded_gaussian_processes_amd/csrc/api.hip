@@ -437,6 +437,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
+    const double* Hr[2] = {H0[0], H0[1]};      // H for the rotation below: a reduced copy when a warm chain's first launch made one
+    int hrn[2] = {ghn[0], ghn[1]};
     VgEigJob ej[2];
     if (warm && subspace) {
         // ---- subspace start (numerically rank-deficient G, e.g. RBF: rank ~20 of 128).  S = d.F is the previous basis after
@@ -456,12 +458,14 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, d.F, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // Z = V G
-            if (from_slabs && ghn[k] > 1)
+            if (from_slabs && ghn[k] > 1) {
                 vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                vg_gemm_add(&g, d.Id, d.m, 1, H0[k], d.m, 1, gdst[k] + (long)d.m * d.m, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            }
         }
         VG_HIP(vg_gemm_launch(&g, st));
         for (int k = 0; k < 2; ++k)
-            if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; }
+            if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; Hr[k] = gdst[k] + (long)c->d[k].m * c->d[k].m; hrn[k] = 1; }
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
@@ -516,9 +520,13 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             vg_gemm_add(&g, extrap ? d.F : d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
-            if (refine && from_slabs && ghn[k] > 1) {        // G is read again after the refinement: leave a reduced copy
-                vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
-                Gr[k] = gdst[k]; grn[k] = 1;
+            if (from_slabs && ghn[k] > 1) {                  // reduced copies for the later readers (G after a refinement, H in the rotation)
+                if (refine) {
+                    vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                    Gr[k] = gdst[k]; grn[k] = 1;
+                }
+                vg_gemm_add(&g, d.Id, d.m, 1, H0[k], d.m, 1, gdst[k] + (long)d.m * d.m, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                Hr[k] = gdst[k] + (long)d.m * d.m; hrn[k] = 1;
             }
         }
         VG_HIP(vg_gemm_launch(&g, st));
@@ -587,8 +595,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         vg_gemm_add(&g, d.Mk, d.m, 1, d.Qt, 1, d.m, d.TM, d.m, d.m, d.m, d.m);      // Mk Q
-        const int ih = vg_gemm_add(&g, H0[k], d.m, 1, d.Qt, 1, d.m, d.TH, d.m, d.m, d.m, d.m);     // H0 Q
-        g.p[ih].a_nslab = ghn[k]; g.p[ih].a_slab = ghs[k];
+        const int ih = vg_gemm_add(&g, Hr[k], d.m, 1, d.Qt, 1, d.m, d.TH, d.m, d.m, d.m, d.m);     // H0 Q
+        g.p[ih].a_nslab = hrn[k]; g.p[ih].a_slab = ghs[k];
     }
     const int ic = vg_gemm_add(&g, C3, m2, 1, d2.Qt, 1, m2, c->T3, (int)m2, (int)(3 * m1), (int)m2, (int)m2);   // [C;C1;C2] Q2
     g.p[ic].a_nslab = ccn; g.p[ic].a_slab = ccs;
