@@ -7,6 +7,10 @@
 2. ref_pins.npz -- outputs of the reference modules that DO import here (torch/numpy/scipy only):
    src/utils/datagenerators.gen_2d (point ordering), src/basis/bspline.B0SplineBasis (mesh bookkeeping),
    src/utils/integrators.integrate_1d (the quad known-answer check).  Data only -- no reference source.
+3. ref_pins_basis.npz -- outputs of the reference's importable inducing-feature bases at fixed inputs:
+   src/basis/fourier.FourierBasisMatern12(M, a, b, ell)(x)  (fourier.py:58-88; float32 arithmetic in the reference) and
+   src/basis/bspline.B1SplineBasis(mesh)(x)  (bspline.py:106-112).  They pin the oracle's vff/b1 Kuf builders and the
+   HIP vggp_factor_build(VGGP_BASIS_VFF / VGGP_BASIS_B1) A-factors on reference-produced numbers.
 """
 import os
 import sys
@@ -152,7 +156,42 @@ def make_ref_pins():
     print("ref pins written")
 
 
+def make_ref_pins_basis():
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        print("no /root/reference: ref_pins_basis.npz left as committed")
+        return
+    sys.path.insert(0, ref)
+    from src.basis.bspline import B1SplineBasis
+    from src.basis.fourier import FourierBasisMatern12
+    rng = np.random.default_rng(3)
+    out = {}
+    # VFF: points inside [a, b), on both boundaries, and outside on either side (the exp(-r/ell) tails)
+    for tag, (M, a, b, ell) in {"vff_a": (5, -0.1, 1.1, 0.25), "vff_b": (12, 0.0, 2.0, 0.6931)}.items():
+        x = np.concatenate([rng.uniform(a, b, 40), [a, b, a - 0.3, a - 0.01, b + 0.02, b + 0.5, 0.5 * (a + b)]])
+        fb = FourierBasisMatern12(M, a, b, ell)
+        Phi = fb(torch.tensor(x))                 # (2M+1) x n; float32 omegas promote against the float64 points
+        out[tag + "_M"], out[tag + "_a"], out[tag + "_b"], out[tag + "_ell"] = np.array(M), np.array(a), np.array(b), np.array(ell)
+        out[tag + "_x"] = x
+        out[tag + "_omegas"] = fb.omegas.numpy()
+        out[tag + "_Phi"] = Phi.double().numpy()
+        out[tag + "_dtype"] = np.array(str(Phi.dtype))
+    # B1: interior points, every knot, both ends, and points outside the mesh
+    for tag, (lo, hi, nk, dt) in {"b1_f64": (0.0, 1.0, 8, torch.float64), "b1_f32": (-1.0, 2.0, 11, torch.float32)}.items():
+        mesh = torch.linspace(lo, hi, nk, dtype=dt)
+        x = np.concatenate([rng.uniform(lo, hi, 40), mesh.double().numpy(), [lo - 0.1, hi + 0.1]])
+        Phi = B1SplineBasis(mesh)(torch.tensor(x))
+        out[tag + "_mesh"] = mesh.numpy()
+        out[tag + "_x"] = x
+        out[tag + "_Phi"] = Phi.double().numpy()
+    np.savez(os.path.join(HERE, "ref_pins_basis.npz"), **out)
+    print("ref basis pins written:", {k: v.shape for k, v in out.items() if k.endswith("_Phi")})
+
+
 if __name__ == "__main__":
+    if "--basis-pins-only" in sys.argv:
+        make_ref_pins_basis()
+        sys.exit(0)
     for k, v in CASES.items():
         make_case(k, v)
     for k, v in MASK_CASES.items():
@@ -161,3 +200,4 @@ if __name__ == "__main__":
         make_new_basis_case(k, v)
     make_1d()
     make_ref_pins()
+    make_ref_pins_basis()

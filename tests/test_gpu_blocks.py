@@ -60,6 +60,28 @@ def test_factor_build_b0(engine):
         assert rel(got.cpu().numpy(), ref) < 1e-12
 
 
+def test_factor_build_vs_reference_basis_pins(engine):
+    """HIP vggp_factor_build(VGGP_BASIS_VFF / VGGP_BASIS_B1) A-factors against outputs of the reference's own importable
+    basis classes (tests/golden/ref_pins_basis.npz: FourierBasisMatern12(M, a, b, ell)(x), fourier.py:58-88 -- float32
+    arithmetic there, hence the tolerance -- and B1SplineBasis(mesh)(x), bspline.py:106-112)."""
+    import os
+    p = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_pins_basis.npz"))
+    for tag in ("vff_a", "vff_b"):
+        M, a, b, ell = int(p[tag + "_M"]), float(p[tag + "_a"]), float(p[tag + "_b"]), float(p[tag + "_ell"])
+        x, om32, ref = p[tag + "_x"], p[tag + "_omegas"], p[tag + "_Phi"]
+        grid = np.concatenate([[a, b], om32.astype(np.float64)])
+        A, dA, K, dK = engine.factor_build("matern12", "vff", torch.tensor(x, device=DEV), torch.tensor(grid, device=DEV), ell)
+        tol = 2e-7 * max(1.0, float(np.abs(om32).max() * np.abs(x - a).max()))
+        assert A.shape == ref.shape and np.abs(A.cpu().numpy() - ref).max() < tol
+        outside = (x < a) | (x >= b)
+        assert np.abs(A.cpu().numpy()[:, outside] - ref[:, outside]).max() < 2e-7
+    for tag, tol in (("b1_f64", 1e-14), ("b1_f32", 1e-6)):
+        mesh, x, ref = p[tag + "_mesh"].astype(np.float64), p[tag + "_x"], p[tag + "_Phi"]
+        A, dA, K, dK = engine.factor_build("matern12", "b1", torch.tensor(x, device=DEV), torch.tensor(mesh, device=DEV), 0.3)
+        assert A.shape == ref.shape and np.abs(A.cpu().numpy() - ref).max() < tol
+        assert float(dA.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("m,kind,ell", [(7, "matern12", 0.3), (64, "matern32", 0.2), (128, "matern52", 0.2),
                                         (128, "rbf", 0.2), (150, "matern32", 0.1), (300, "rbf", 0.05),
                                         (1024, "matern32", 0.05)])
@@ -79,8 +101,11 @@ def test_cholesky_inverse(engine, m, kind, ell):
 
 
 @pytest.mark.parametrize("block", [False, True], ids=["scalar", "block"])
-@pytest.mark.parametrize("m,kind", [(1, "matern12"), (9, "matern12"), (64, "rbf"), (128, "matern32"), (150, "matern12")])
+@pytest.mark.parametrize("m,kind", [(1, "matern12"), (9, "matern12"), (64, "rbf"), (128, "matern32"), (150, "matern12"),
+                                    (185, "matern12"), (200, "matern32"), (256, "matern12"), (256, "rbf")])
 def test_eigh(engine, m, kind, block):
+    if block and m > 150:
+        pytest.skip("the block-Jacobi variant exists for m <= 128 (larger m falls back to the scalar solver: covered at 150)")
     xx = np.linspace(0, 1, 4 * m + 3)
     f = Kr.Factor("points", kind, np.linspace(0, 1, m), xx)
     d = Kr.dim_prepare(f, 0.2, 1.0)

@@ -106,3 +106,73 @@ def test_sharded_rbf_runs_the_subspace_start(engine):
             assert abs(e - ref.elbo) <= 1e-8 * abs(ref.elbo)
             assert np.abs(g - ref.grad).max() <= 1e-6 * np.abs(ref.grad).max()
     assert all(r[1][NSTEP - 1][2] < 60 for r in res), [r[1][NSTEP - 1][2] for r in res]
+
+
+# ---- BASELINE configs[3]: 4096 x 4096 RBF grid, sharded 4-way along the slow storage axis, m_d = 128 -----------------
+C4_N, C4_M, C4_WORLD = 4096, 128, 4
+C4_THETA = [0.2, 0.2, 1.0, 1.0, 0.0025]
+C4_STEPS = 3
+
+
+def _config4_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import dense as D
+    from variational_gridded_gaussian_processes_amd import Engine
+    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, x1, x2 = D.gen_grid(C4_N, C4_N)
+        del X
+        rows = shard_rows(C4_N, rank, world)
+        assert rows.stop - rows.start == C4_N // world           # the 1024-row x 4096 slab of the config
+        g = np.linspace(0, 1, C4_M)
+        eng = Engine(0)
+        eng.plan("rbf", "points", g, x1, "rbf", "points", g, x2[rows], n_total=C4_N * C4_N, warm_start=True)
+        Y = torch.tensor(y.reshape(C4_N, C4_N)[rows], device="cuda:0")
+        sh = ShardedStep(eng)
+        yy = sh.sumsq_total(Y)
+        out = []
+        for k in range(C4_STEPS):
+            th = np.array(C4_THETA) * (1.0 + 0.01 * k)
+            e, gr, info = sh.step(Y, yy, th)
+            out.append((e, gr, info["jitter"]))
+        mean, var = eng.qv()
+        q.put((rank, out, mean.cpu().numpy(), var.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_four_ranks_1024x4096_slabs_vs_structured_oracle(engine):
+    """BASELINE configs[3] as specified: 4096 x 4096 RBF grid, m_d = 128, four ranks each owning a 1024-row x 4096 slab,
+    ONE all-reduce per step (gloo carries it here: four processes share the one GPU of the test box; RCCL on the node).
+    Every rank's value / gradient / q(v) against oracle/kron.py on the FULL grid: value 1e-8, gradient 1e-6."""
+    from oracle import dense as D, kron as Kr
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_config4_worker, args=(r, C4_WORLD, port, q)) for r in range(C4_WORLD)]
+    for p in procs:
+        p.start()
+    X, y, x1, x2 = D.gen_grid(C4_N, C4_N)          # the oracle runs while the ranks do
+    del X
+    g = np.linspace(0, 1, C4_M)
+    f1, f2 = Kr.Factor("points", "rbf", g, x1), Kr.Factor("points", "rbf", g, x2)
+    refs = [Kr.elbo_step(y.reshape(C4_N, C4_N), f1, f2, np.array(C4_THETA) * (1.0 + 0.01 * k)) for k in range(C4_STEPS)]
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for k, ref in enumerate(refs):
+        for rank, out, _, _ in res:
+            e, gr, jit = out[k]
+            assert tuple(jit) == (ref.d1.jit, ref.d2.jit)
+            assert abs(e - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, rank, e, ref.elbo)
+            assert np.abs(gr - ref.grad).max() <= 1e-6 * np.abs(ref.grad).max(), (k, rank)
+        assert all(r[1][k][0] == res[0][1][k][0] for r in res)         # identical on every rank (no broadcast needed)
+    rm, rv = Kr.q_v(refs[-1])
+    for _, _, mean, var in res:
+        assert np.abs(mean - rm).max() <= 1e-6 * np.abs(rm).max()
+        assert np.abs(var - rv).max() <= 1e-6 * np.abs(rv).max()

@@ -232,6 +232,63 @@ def test_config5_shape_masked_b0_vs_structured_oracle(engine):
     assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-6
 
 
+def test_config5_full_size_masked_2048_vs_structured_oracle(engine):
+    """BASELINE configs[4] at its size: 2048 x 2048 grid, Matern-1/2 B0 model, Bernoulli(0.7) keep with default_rng(1)
+    (~30 % missing), m_d = 32 (M = 1024, exact masked mode) against Kr.elbo_step_masked; then two more steps of a
+    hyper-parameter trajectory (the fit loop of the config) stay on the oracle."""
+    n, nk = 2048, 33
+    X, y, x1, x2 = D.gen_grid(n, n)
+    del X
+    Wn = (np.random.default_rng(1).uniform(size=(n, n)) < 0.7).astype(np.float64)
+    assert 0.29 < 1.0 - Wn.mean() < 0.31
+    g = np.linspace(0, 1, nk)
+    f1, f2 = Kr.Factor("b0", "matern12", g, x1), Kr.Factor("b0", "matern12", g, x2)
+    engine.plan("matern12", "b0", g, x1, "matern12", "b0", g, x2)
+    W = torch.tensor(Wn, device=DEV)
+    Ym = torch.tensor(y.reshape(n, n), device=DEV) * W
+    yy = engine.sumsq(Ym)
+    for k in range(3):
+        theta = np.array([0.2, 0.2, 1.0, 1.0, 0.0025]) * (1.0 + 0.02 * k)
+        ref = Kr.elbo_step_masked(y.reshape(n, n), Wn, f1, f2, theta)
+        elbo, grad, info = engine.elbo_step_masked(Ym, W, float(Wn.sum()), yy, theta)
+        assert info["status"] == 0
+        assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), k
+        assert rel(grad, ref.grad) < 1e-6, k
+    mean, var = engine.qv_masked()
+    rm, rv = Kr.q_v_masked(ref)
+    assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-6
+    # size-independent property: with everything observed the masked solver equals the Kronecker (eigen) path
+    ones = torch.ones_like(W)
+    Yf = torch.tensor(y.reshape(n, n), device=DEV)
+    e_m, g_m, _ = engine.elbo_step_masked(Yf, ones, float(n * n), engine.sumsq(Yf), theta)
+    e_k, g_k, _ = engine.elbo_step(Yf, engine.sumsq(Yf), theta)
+    assert abs(e_m - e_k) <= 1e-8 * abs(e_k) and rel(g_m, g_k) < 1e-6
+
+
+@pytest.mark.parametrize("kind,n", [("matern32", 512), ("rbf", 384), ("matern12", 300)])
+def test_md256_elbo_step_vs_structured_oracle(engine, kind, n):
+    """m_d = 256 (the top of the m_d sweep of SURVEY.md section 8d and of vggp_plan's range): the factors no longer fit one
+    workgroup's LDS, so the blocked Cholesky and the global-memory Jacobi body (vg_jacobi_body<false>, 184 < m <= 256)
+    carry the step; cold step + warm-started trajectory against oracle/kron.py."""
+    m = 256
+    X, y, x1, x2 = D.gen_grid(n, n)
+    g = np.linspace(0, 1, m)
+    f1, f2 = Kr.Factor("points", kind, g, x1), Kr.Factor("points", kind, g, x2)
+    engine.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=True)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    yy = engine.sumsq(Y)
+    for k in range(4):
+        theta = np.array([0.2, 0.25, 1.0, 0.9, 0.01]) * (1.0 + 0.01 * k)
+        ref = Kr.elbo_step(y.reshape(n, n), f1, f2, theta)
+        elbo, grad, info = engine.elbo_step(Y, yy, theta)
+        assert info["status"] == 0 and info["jitter"] == (ref.d1.jit, ref.d2.jit), (k, info)
+        assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, elbo, ref.elbo)
+        assert rel(grad, ref.grad) < 1e-6, k
+    mean, var = engine.qv()
+    rm, rv = Kr.q_v(ref)
+    assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-6
+
+
 def test_failed_step_resets_the_warm_start(engine):
     """A step that fails (NaN data -> not positive definite is not reachable from data, so poison the grid instead) must
     not leave its bases behind: the following valid steps start cold and are correct."""

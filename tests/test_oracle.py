@@ -152,6 +152,38 @@ def test_reference_pins():
     assert np.abs(exact - p["quad_areas"]).max() < 1e-12
 
 
+def _vff_tol(om, x, a):
+    """The reference evaluates the Fourier features in float32 (float32 omegas against 0-dim float64 points,
+    fourier.py:33-41), so its cos/sin arguments carry a float32 rounding of relative size 6e-8."""
+    return 2e-7 * max(1.0, float(np.abs(om).max() * np.abs(x - a).max()))
+
+
+def test_reference_basis_pins():
+    """The oracle's VFF / B1 Kuf builders against outputs of the reference's own importable basis classes
+    (FourierBasisMatern12(M, a, b, ell)(x), fourier.py:58-88; B1SplineBasis(mesh)(x), bspline.py:106-112) committed in
+    tests/golden/ref_pins_basis.npz by make_golden.py."""
+    p = np.load(os.path.join(GOLD, "ref_pins_basis.npz"))
+    for tag in ("vff_a", "vff_b"):
+        M, a, b, ell = int(p[tag + "_M"]), float(p[tag + "_a"]), float(p[tag + "_b"]), float(p[tag + "_ell"])
+        x, om32 = p[tag + "_x"], p[tag + "_omegas"]
+        assert om32.dtype == np.float32 and np.array_equal(om32, D.vff_omegas(M, a, b).numpy())
+        ref = p[tag + "_Phi"]
+        assert ref.shape == (2 * M + 1, len(x))
+        tol = _vff_tol(om32, x, a)
+        got = D.vff_Kuf_along_dim(a, b, torch.tensor(om32), torch.tensor(ell, dtype=torch.float64), torch.tensor(x)).numpy()
+        assert np.abs(got - ref).max() < tol
+        A, _ = Kr.vff_A(a, b, om32.astype(np.float64), x, ell)
+        assert np.abs(A - ref).max() < tol
+        outside = (x < a) | (x >= b)          # the exp(-r/ell) tails carry no float32 argument blow-up
+        assert outside.sum() >= 4 and np.abs(A[:, outside] - ref[:, outside]).max() < 2e-7
+    for tag, tol in (("b1_f64", 1e-15), ("b1_f32", 1e-6)):
+        mesh, x, ref = p[tag + "_mesh"], p[tag + "_x"], p[tag + "_Phi"]
+        got = D.b1_Kuf_along_dim(torch.tensor(mesh), torch.tensor(x)).numpy()
+        assert np.array_equal(got, ref)       # same formula on the same (possibly float32-born) knots: exact
+        A, _ = Kr.b1_A(mesh.astype(np.float64), x)
+        assert np.abs(A - ref).max() < tol    # kron.b1_A assumes a uniform spacing; a float32 linspace is uniform to 1e-7
+
+
 def test_b0_closed_forms_are_cell_integrals():
     """_Kuu_along_dim / _Kuf_along_dim (kronecker_structure.py:723-790) == numerical cell integrals of exp(-|.|/l)."""
     import scipy.integrate as si

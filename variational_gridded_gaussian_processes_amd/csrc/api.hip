@@ -53,7 +53,7 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
     int ndev = 0;
     VG_HIP(hipGetDeviceCount(&ndev));
     VG_REQUIRE(device >= 0 && device < ndev, "vggp_create: device %d out of range (%d devices)", device, ndev);
-    VG_HIP(hipSetDevice(device));
+    VG_ENTER_DEVICE(device);
     hipDeviceProp_t prop;
     VG_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -82,8 +82,10 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
 
 extern "C" int vggp_destroy(vggp_ctx* c) {
     if (!c) return VGGP_OK;
-    (void)hipSetDevice(c->device);
+    VgDeviceGuard guard;
+    (void)guard.enter(c->device);
     for (int i = 0; i < 12; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    for (int i = 0; i < VGGP_NSTAGE + 2; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     vg_masked_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->arena) (void)hipFree(c->arena);
@@ -251,7 +253,7 @@ static int check_dim(int kind, int basis, long n, long m, const char* which) {
 
 extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     if (!c || !desc) { vg_set_error("vggp_plan: null argument"); return VGGP_EINVAL; }
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     int rc;
     if ((rc = check_dim(desc->kind1, desc->basis1, desc->n1, desc->m1, "dimension 1"))) return rc;
     if ((rc = check_dim(desc->kind2, desc->basis2, desc->n2, desc->m2, "dimension 2"))) return rc;
@@ -789,7 +791,7 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
 extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double theta[5], double* payload, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_partials: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(Y && theta && payload, "vggp_elbo_partials: null argument");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = set_theta(c, theta);
     if (rc) return rc;
@@ -809,7 +811,7 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
                                 double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned || !c->have_partials) { vg_set_error("vggp_elbo_finish: call vggp_elbo_partials first"); return VGGP_ESTATE; }
     VG_REQUIRE(payload && theta && elbo_out && grad_out, "vggp_elbo_finish: null argument");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = set_theta(c, theta);
     if (rc) return rc;
@@ -829,7 +831,7 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
                               double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(Y && theta && elbo_out && grad_out, "vggp_elbo_step: null argument");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = set_theta(c, theta);
     if (rc) return rc;
@@ -866,8 +868,8 @@ static int build_RQ(vggp_ctx* c, hipStream_t st) {
 extern "C" int vggp_qv(vggp_ctx* c, double* mean, double* var, void* stream) {
     if (!c || !c->have_step) { vg_set_error("vggp_qv: no finished ELBO step"); return VGGP_ESTATE; }
     VG_REQUIRE(mean && var, "vggp_qv: null output");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     int rc = build_RQ(c, st);
@@ -903,8 +905,8 @@ __global__ void vg_kron_rows_kernel(const double* R1, const double* R2, const do
 extern "C" int vggp_qv_cov(vggp_ctx* c, double* cov, void* stream) {
     if (!c || !c->have_step) { vg_set_error("vggp_qv_cov: no finished ELBO step"); return VGGP_ESTATE; }
     VG_REQUIRE(cov, "vggp_qv_cov: null output");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m1 = c->desc.m1, m2 = c->desc.m2, M = m1 * m2;
     VG_REQUIRE(M <= 8192, "vggp_qv_cov: M=%ld too large for a dense covariance (use vggp_qv for mean/variance)", M);
     int rc = build_RQ(c, st);
@@ -929,8 +931,8 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
                               void* stream) {
     if (!c || !c->have_step) { vg_set_error("vggp_posterior: no finished ELBO step"); return VGGP_ESTATE; }
     VG_REQUIRE(xs1 && xs2 && mean && var && ns >= 0, "vggp_posterior: bad argument");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     const long chunk = std::min<long>(ns, 8192);
     if (ns == 0) return VGGP_OK;
@@ -981,8 +983,8 @@ extern "C" int vggp_readout(vggp_ctx* c, const double* C1, int64_t mv1, const do
                             const double* kd2, double* mean, double* var, int flags, void* stream) {
     if (!c || !c->have_step) { vg_set_error("vggp_readout: no finished ELBO step"); return VGGP_ESTATE; }
     VG_REQUIRE(C1 && C2 && kd1 && kd2 && mean && var && mv1 >= 1 && mv2 >= 1, "vggp_readout: bad argument");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     const size_t need = (size_t)(3 * (m1 * mv1 + m2 * mv2) + 2 * m1 * mv2) * sizeof(double);
     int rc = vg_ensure_misc(c, need);
@@ -1033,9 +1035,9 @@ extern "C" int vggp_factor_build(vggp_ctx* c, int kind, int basis, const double*
     VG_REQUIRE(n >= 0 && m >= 1 && ell > 0.0, "vggp_factor_build: bad sizes / lengthscale");
     VG_REQUIRE(grid || basis == VGGP_BASIS_ONE, "vggp_factor_build: null grid");
     VG_REQUIRE((x || !(A0 || dA0)), "vggp_factor_build: null x");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     VgFactorJob j{x, grid, n > 0 ? A0 : nullptr, n > 0 ? dA0 : nullptr, K0, dK0, (int)n, (int)m, kind, basis, -1, ell, flags};
-    VG_HIP(vg_factor_build_launch(&j, 1, nullptr, (hipStream_t)stream));
+    VG_HIP(vg_factor_build_launch(&j, 1, nullptr, stream ? (hipStream_t)stream : c->own_stream));
     return VGGP_OK;
 }
 
@@ -1050,8 +1052,8 @@ extern "C" int vggp_cholesky_inverse(vggp_ctx* c, const double* K, int64_t m, do
                                      void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(K && L && Linv && m >= 1 && m <= 8192, "vggp_cholesky_inverse: bad argument (1 <= m <= 8192)");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     if (m > 128) {
         // beyond one workgroup: blocked factorisation (128-wide panels by the single-workgroup kernel, the rest by MFMA
         // GEMMs); the jitter schedule is walked on the host, one attempt per level
@@ -1109,8 +1111,8 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
                          void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(G && lam && Qt && m >= 1 && m <= 256, "vggp_eigh: bad argument (1 <= m <= 256)");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m2e = m + (m & 1);
     const int max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
     const size_t logb = (vg_eigh_log_bytes((int)m) + 15) & ~size_t(15);
@@ -1145,11 +1147,11 @@ extern "C" int vggp_gemm(vggp_ctx* c, const double* A, int64_t sa_m, int64_t sa_
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N, "vggp_gemm: bad argument");
     VG_REQUIRE(M < (1L << 30) && N < (1L << 30) && K < (1L << 30), "vggp_gemm: dimension too large");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     VgGemmBatch g;
     vg_gemm_init(&g);
     vg_gemm_add(&g, A, sa_m, sa_k, B, sb_k, sb_n, C, (int)ldc, (int)M, (int)N, (int)K);
-    VG_HIP(vg_gemm_launch(&g, (hipStream_t)stream));
+    VG_HIP(vg_gemm_launch(&g, stream ? (hipStream_t)stream : c->own_stream));
     return VGGP_OK;
 }
 
@@ -1157,8 +1159,8 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, con
                                const double* Y, double* X, void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(L1inv && L2inv && Y && X && n1 >= 1 && n2 >= 1, "vggp_kron_solve: bad argument");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = vg_ensure_misc(c, 2 * (size_t)n1 * n2 * sizeof(double));
     if (rc) return rc;
     double* T1 = (double*)c->misc;
@@ -1195,7 +1197,7 @@ extern "C" int vggp_debug_read_misc(vggp_ctx* c, void* host, int64_t bytes) {
 
 extern "C" int vggp_profile(vggp_ctx* c, int enable) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     if (enable && !c->ev[0])
         for (int i = 0; i < VGGP_NSTAGE + 2; ++i) VG_HIP(hipEventCreate(&c->ev[i]));
     c->prof = enable != 0;
@@ -1213,8 +1215,8 @@ extern "C" int vggp_profile_read(vggp_ctx* c, double ms_out[VGGP_NSTAGE], int32_
 extern "C" int vggp_sumsq(vggp_ctx* c, const double* y, int64_t n, double* out, void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_REQUIRE(y && out && n >= 0, "vggp_sumsq: bad argument");
-    VG_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     VG_HIP(vg_sumsq_launch(y, n, c->sumsq_partial, c->sumsq_out, st));
     VG_HIP(hipMemcpyAsync(out, c->sumsq_out, sizeof(double), hipMemcpyDeviceToHost, st));
     VG_HIP(hipStreamSynchronize(st));

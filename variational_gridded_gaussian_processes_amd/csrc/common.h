@@ -25,6 +25,21 @@ void vg_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// Every C entry point runs on the context's device and restores the caller's current device on return (the library never
+// changes the calling thread's device as a side effect).
+struct VgDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != dev) { e = hipSetDevice(dev); switched = (e == hipSuccess); }
+        return e;
+    }
+    ~VgDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define VG_ENTER_DEVICE(dev) VgDeviceGuard vg_dev_guard_; VG_HIP(vg_dev_guard_.enter(dev))
+
 // ---- batched strided GEMM descriptors (passed by value as kernel argument) -----
 #define VG_GEMM_MAXP 12
 #define VG_BM 64

@@ -305,10 +305,11 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
                                      void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step_masked: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(Ym && W && theta && elbo_out && grad_out, "vggp_elbo_step_masked: null argument");
+    c->have_masked = false;          // a failed step must not leave an earlier step's state readable (qv_masked / posterior_masked)
     const long m1 = c->desc.m1, m2 = c->desc.m2, n1 = c->desc.n1, n2 = c->desc.n2, M = m1 * m2;
     VG_REQUIRE(M <= 8192, "vggp_elbo_step_masked: M = m1*m2 = %ld too large for the dense masked solver (<= 8192)", M);
     VG_REQUIRE(m1 * m1 * n1 < (1L << 31) && m2 * m2 * n2 < (1L << 31) && M * M < (1L << 31) * 4, "masked problem too large");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     for (int i = 0; i < 5; ++i) {
         VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
@@ -427,7 +428,7 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
 extern "C" int vggp_qv_masked(vggp_ctx* c, double* mean, double* var, void* stream) {
     if (!c || !c->have_masked || !c->masked) { vg_set_error("vggp_qv_masked: no finished masked step"); return VGGP_ESTATE; }
     VG_REQUIRE(mean && var, "vggp_qv_masked: null output");
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
     const long m1 = w.m1, m2 = w.m2, M = w.M;
@@ -469,7 +470,7 @@ extern "C" int vggp_posterior_masked(vggp_ctx* c, const double* xs1, const doubl
     if (!c || !c->have_masked || !c->masked) { vg_set_error("vggp_posterior_masked: no finished masked step"); return VGGP_ESTATE; }
     VG_REQUIRE(xs1 && xs2 && mean && var && ns >= 0, "vggp_posterior_masked: bad argument");
     if (ns == 0) return VGGP_OK;
-    VG_HIP(hipSetDevice(c->device));
+    VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
     const long m1 = w.m1, m2 = w.m2, M = w.M;

@@ -23,8 +23,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    """torch's current stream ON THE ENGINE'S DEVICE (not on torch's current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _dvec(x) -> np.ndarray:
@@ -57,6 +58,7 @@ class Engine:
         self._h = h
         self.m1 = self.m2 = self.n1 = self.n2 = 0
         self.planned = False
+        self.plan_token = 0          # bumped by every plan(): a model sharing this engine re-plans when it is not the last planner
 
     def close(self):
         if getattr(self, "_h", None):
@@ -92,6 +94,7 @@ class Engine:
         self.m1, self.m2, self.n1, self.n2 = m1, m2, len(x1), len(x2)
         self.payload_len = int(self.lib.vggp_payload_len(self._h))
         self.planned = True
+        self.plan_token += 1
 
     @property
     def workspace_bytes(self) -> int:
@@ -110,7 +113,7 @@ class Engine:
         grad = (C.c_double * 5)()
         info = Info()
         check(self.lib.vggp_elbo_step(self._h, _ptr(Y), float(yy_total), th, C.byref(elbo), grad, C.byref(info),
-                                      _stream()))
+                                      _stream(self.device)))
         return elbo.value, np.array(list(grad)), self._info(info)
 
     def elbo_step_masked(self, Ym: torch.Tensor, W: torch.Tensor, n_obs: float, yy_obs: float, theta: Sequence[float]):
@@ -122,13 +125,13 @@ class Engine:
         grad = (C.c_double * 5)()
         info = Info()
         check(self.lib.vggp_elbo_step_masked(self._h, _ptr(Ym), _ptr(W), float(n_obs), float(yy_obs), th, C.byref(elbo),
-                                             grad, C.byref(info), _stream()))
+                                             grad, C.byref(info), _stream(self.device)))
         return elbo.value, np.array(list(grad)), self._info(info)
 
     def qv_masked(self) -> Tuple[torch.Tensor, torch.Tensor]:
         mean = torch.empty(self.m1, self.m2, dtype=torch.float64, device=self.device)
         var = torch.empty_like(mean)
-        check(self.lib.vggp_qv_masked(self._h, _ptr(mean), _ptr(var), _stream()))
+        check(self.lib.vggp_qv_masked(self._h, _ptr(mean), _ptr(var), _stream(self.device)))
         return mean, var
 
     def elbo_partials(self, Y: torch.Tensor, theta: Sequence[float], payload: Optional[torch.Tensor] = None):
@@ -136,7 +139,7 @@ class Engine:
         if payload is None:
             payload = torch.empty(self.payload_len, dtype=torch.float64, device=self.device)
         th = (C.c_double * 5)(*[float(t) for t in theta])
-        check(self.lib.vggp_elbo_partials(self._h, _ptr(Y), th, _ptr(payload), _stream()))
+        check(self.lib.vggp_elbo_partials(self._h, _ptr(Y), th, _ptr(payload), _stream(self.device)))
         return payload
 
     def elbo_finish(self, payload: torch.Tensor, yy_total: float, theta: Sequence[float]):
@@ -145,7 +148,7 @@ class Engine:
         grad = (C.c_double * 5)()
         info = Info()
         check(self.lib.vggp_elbo_finish(self._h, _ptr(payload), float(yy_total), th, C.byref(elbo), grad,
-                                        C.byref(info), _stream()))
+                                        C.byref(info), _stream(self.device)))
         return elbo.value, np.array(list(grad)), self._info(info)
 
     @staticmethod
@@ -156,13 +159,13 @@ class Engine:
     def qv(self) -> Tuple[torch.Tensor, torch.Tensor]:
         mean = torch.empty(self.m1, self.m2, dtype=torch.float64, device=self.device)
         var = torch.empty_like(mean)
-        check(self.lib.vggp_qv(self._h, _ptr(mean), _ptr(var), _stream()))
+        check(self.lib.vggp_qv(self._h, _ptr(mean), _ptr(var), _stream(self.device)))
         return mean, var
 
     def qv_cov(self) -> torch.Tensor:
         M = self.m1 * self.m2
         cov = torch.empty(M, M, dtype=torch.float64, device=self.device)
-        check(self.lib.vggp_qv_cov(self._h, _ptr(cov), _stream()))
+        check(self.lib.vggp_qv_cov(self._h, _ptr(cov), _stream(self.device)))
         return cov
 
     def readout(self, C1: torch.Tensor, C2: torch.Tensor, kd1: torch.Tensor, kd2: torch.Tensor, literal: bool = True):
@@ -175,7 +178,7 @@ class Engine:
         mean = torch.empty(C1.shape[0], C2.shape[0], dtype=torch.float64, device=self.device)
         var = torch.empty_like(mean)
         check(self.lib.vggp_readout(self._h, _ptr(C1), C1.shape[0], _ptr(C2), C2.shape[0], _ptr(kd1), _ptr(kd2), _ptr(mean),
-                                    _ptr(var), 1 if literal else 0, _stream()))
+                                    _ptr(var), 1 if literal else 0, _stream(self.device)))
         return mean, var
 
     def posterior_masked(self, x_star: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -191,7 +194,7 @@ class Engine:
         ns = xs1.shape[0]
         mean = torch.empty(ns, dtype=torch.float64, device=self.device)
         var = torch.empty_like(mean)
-        check(getattr(self.lib, _fn)(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(mean), _ptr(var), _stream()))
+        check(getattr(self.lib, _fn)(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(mean), _ptr(var), _stream(self.device)))
         return mean, var
 
     # -- building blocks ------------------------------------------------------------------------------
@@ -202,14 +205,14 @@ class Engine:
         o = dict(dtype=torch.float64, device=self.device)
         A, dA, K, dK = torch.empty(m, n, **o), torch.empty(m, n, **o), torch.empty(m, m, **o), torch.empty(m, m, **o)
         check(self.lib.vggp_factor_build(self._h, KIND[kind], BASIS[basis], _ptr(x), n, _ptr(grid), m, float(ell), int(flags),
-                                         _ptr(A), _ptr(dA), _ptr(K), _ptr(dK), _stream()))
+                                         _ptr(A), _ptr(dA), _ptr(K), _ptr(dK), _stream(self.device)))
         return A, dA, K, dK
 
     def cholesky_inverse(self, K: torch.Tensor):
         m = K.shape[0]
         L, Li = torch.empty_like(K), torch.empty_like(K)
         jit = C.c_double()
-        check(self.lib.vggp_cholesky_inverse(self._h, _ptr(K), m, _ptr(L), _ptr(Li), C.byref(jit), _stream()))
+        check(self.lib.vggp_cholesky_inverse(self._h, _ptr(K), m, _ptr(L), _ptr(Li), C.byref(jit), _stream(self.device)))
         return L, Li, jit.value
 
     def eigh(self, G: torch.Tensor, block: bool = False):
@@ -219,7 +222,7 @@ class Engine:
         Qt = torch.empty_like(G)
         sw = C.c_int32()
         check(self.lib.vggp_eigh(self._h, _ptr(G), m, _ptr(lam), _ptr(Qt), C.byref(sw),
-                                 _lib.FLAG_BLOCK_JACOBI if block else 0, _stream()))
+                                 _lib.FLAG_BLOCK_JACOBI if block else 0, _stream(self.device)))
         return lam, Qt, sw.value
 
     def gemm(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
@@ -232,13 +235,13 @@ class Engine:
             if not (t.is_cuda and t.dtype == torch.float64):
                 raise TypeError("gemm operands must be float64 GPU tensors")
         check(self.lib.vggp_gemm(self._h, A.data_ptr(), A.stride(0), A.stride(1), B.data_ptr(), B.stride(0),
-                                 B.stride(1), Cm.data_ptr(), N, M, N, K, _stream()))
+                                 B.stride(1), Cm.data_ptr(), N, M, N, K, _stream(self.device)))
         return Cm
 
     def kron_solve(self, L1inv: torch.Tensor, L2inv: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
         n1, n2 = Y.shape
         X = torch.empty_like(Y)
-        check(self.lib.vggp_kron_solve(self._h, _ptr(L1inv), n1, _ptr(L2inv), n2, _ptr(Y), _ptr(X), _stream()))
+        check(self.lib.vggp_kron_solve(self._h, _ptr(L1inv), n1, _ptr(L2inv), n2, _ptr(Y), _ptr(X), _stream(self.device)))
         return X
 
     def profile(self, enable: bool = True) -> None:
@@ -254,5 +257,5 @@ class Engine:
 
     def sumsq(self, y: torch.Tensor) -> float:
         out = C.c_double()
-        check(self.lib.vggp_sumsq(self._h, _ptr(y), y.numel(), C.byref(out), _stream()))
+        check(self.lib.vggp_sumsq(self._h, _ptr(y), y.numel(), C.byref(out), _stream(self.device)))
         return out.value

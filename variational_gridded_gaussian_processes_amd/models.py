@@ -192,6 +192,7 @@ class KroneckerStructure(torch.nn.Module):
         self._engine = engine if engine is not None else Engine()
         self._warm = warm_start
         self._planned = False
+        self._plan_token, self._plan_key = -1, None
         self.last_info = None
         self._x1, self._x2, W, flat = _detect_grid(X)
         n2, n1 = len(self._x2), len(self._x1)
@@ -217,11 +218,15 @@ class KroneckerStructure(torch.nn.Module):
         return mesh is not None and mesh.dtype == torch.float32
 
     def _plan(self):
-        if not self._planned:
-            basis, g1, g2 = self._basis()
+        """(Re)plan the engine when this model is not its last planner (an Engine may be shared between models: the plan --
+        factors, basis, meshes -- lives in the engine) or when its inducing description changed since the last plan."""
+        basis, g1, g2 = self._basis()
+        key = (basis, np.asarray(g1).tobytes(), np.asarray(g2).tobytes())
+        if not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
             self._engine.plan(self.kind, basis, g1, self._x1, self.kind, basis, g2, self._x2, warm_start=self._warm,
                               b0_f32_kdelta=self._f32_mesh())
             self._planned = True
+            self._plan_token, self._plan_key = self._engine.plan_token, key
 
     def _theta(self) -> torch.Tensor:
         return torch.stack([self.kernel_1.base_kernel.lengthscale.reshape(()),
@@ -523,6 +528,7 @@ class _SparseGP1D(torch.nn.Module):
         self._engine = engine if engine is not None else Engine()
         self._warm = warm_start
         self._planned = False
+        self._plan_token, self._plan_key = -1, None
         self._masked = False
         self.last_info = None
         self._x = torch.as_tensor(X, dtype=torch.float64).reshape(-1).numpy().copy()
@@ -533,12 +539,14 @@ class _SparseGP1D(torch.nn.Module):
         raise NotImplementedError
 
     def _plan(self):
-        if not self._planned:
-            basis, g = self._basis()
+        basis, g = self._basis()
+        key = (basis, np.asarray(g).tobytes())
+        if not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
             mesh = getattr(self, "mesh", None)
             self._engine.plan(self.kind, basis, g, self._x, "matern12", "one", None, np.zeros(1), warm_start=self._warm,
                               b0_f32_kdelta=mesh is not None and mesh.dtype == torch.float32)
             self._planned = True
+            self._plan_token, self._plan_key = self._engine.plan_token, key
 
     def _theta(self):
         one = torch.ones((), dtype=torch.float64)
