@@ -424,7 +424,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
                           bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
-    if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 5 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 6 * sizeof(double), hipMemcpyHostToDevice, st));
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     // from_slabs (fused warm step): G, H, C are still split-K slabs; every consumer below is a GEMM that sums them on load
@@ -496,6 +496,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             sj[k] = VgEigJob{d.Hs, d.lam_s, d.Ws, nullptr, d.gwork2, d.rotlog2, d.roundlog2, d.counters2, d.sub_r, d.max_rounds,
                              (long)vg_eigh_log_bytes(d.m), 0};
             sj[k].perm = d.perm2;
+            sj[k].err = d.status + 1;
         }
         VG_HIP(vg_eigh_launch(sj, 2, st));                                                                           // Ritz pairs
         vg_gemm_init(&g);
@@ -585,6 +586,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
         ej[k].perm = d.perm;
         ej[k].cp_src = d.QtPrev; ej[k].cp_dst = d.QtPrev2;      // the basis before last, for the next extrapolation
+        ej[k].err = d.status + 1;      // replay timeout flag (folded into the step status by the final kernel)
         ej[k].polish0 = (warm && refine) ? 1 : 0;
         ej[k].sparse_first = (warm && subspace) ? 1 : 0;
     }
@@ -718,6 +720,7 @@ static int set_theta(vggp_ctx* c, const double theta[5]) {
         VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
         c->h_theta[i] = theta[i];
     }
+    c->h_theta[5] = (double)(++c->seq);        // travels through the step and comes back in the pinned result block
     return VGGP_OK;
 }
 
@@ -732,6 +735,13 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
             if (c->ev_set[a] && c->ev_set[b] && hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess) c->prof_ms[i] += ms;
         }
         c->prof_steps++;
+    }
+    if (c->h_out->seq != c->h_theta[5]) {       // the block was not written by THIS step (a launch was lost or reordered)
+        vg_set_error("step %.0f: the result block carries sequence number %.0f (stale results)", c->h_theta[5], c->h_out->seq);
+        c->warm_run = 0;
+        for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+        c->have_step = false;
+        return VGGP_ESTATE;
     }
     *elbo_out = c->h_out->out[0];
     for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
@@ -1128,17 +1138,18 @@ extern "C" int vggp_eigh(vggp_ctx* c, const double* G, int64_t m, double* lam, d
     int* perm = counters + 16;
     VgClearArgs clr;
     clr.n = 1;
-    clr.ptr[0] = counters; clr.nwords[0] = 4;
+    clr.ptr[0] = counters; clr.nwords[0] = 8;
     VG_HIP(vg_clear_launch(&clr, st));
     VgEigJob j{G, lam, Qt, nullptr, gwork, rotlog, roundlog, counters, (int)m, max_rounds, (long)logb,
                (flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
     j.perm = perm;
+    j.err = counters + 4;
     VG_HIP(vg_eigh_launch(&j, 1, st));
-    int hc[4] = {0, 0, 0, 0};
+    int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     VG_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
     VG_HIP(hipStreamSynchronize(st));
     if (sweeps_out) *sweeps_out = hc[1] & 0xff;
-    if (hc[2]) { vg_set_error("vggp_eigh: no convergence"); return VGGP_ENOCONV; }
+    if (hc[2] || hc[4]) { vg_set_error("vggp_eigh: no convergence"); return VGGP_ENOCONV; }
     return VGGP_OK;
 }
 

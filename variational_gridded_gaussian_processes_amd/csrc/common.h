@@ -145,6 +145,7 @@ struct VgEigJob {
     int* perm = nullptr;   // [m] scratch: rank of eigenpair i in decreasing order (scalar variant; null = leave unsorted)
     int fast_switch = 112; // fixed-address dense sweeps (m2 <= 128) while >= fast_switch/256 of a sweep's pairs rotate; 0 = off
     int polish = 1;        // dense phase: replace the remaining sweeps by a first-order polish when its a-priori bound allows
+    int* err = nullptr;    // optional device word the replay workgroups OR a 1 into when they give up waiting for the producer
     int polish0 = 0;       // also try the polish before the first sweep (the start basis was refined by vg_refine_launch)
     int sparse_first = 0;  // skip the dense phase: the start basis already block-diagonalises G (subspace start), a few elements remain
 };
@@ -163,11 +164,12 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
 hipError_t vg_eigh_setup();
 
 // ---- m-space elementwise / reductions (mspace.hip) -----------------------------
-struct VgHostOut {          // pinned readback block
+struct VgHostOut {          // pinned readback block (one 128-byte burst)
     double out[8];
     double jitter[2];
     int counters[2][4];
     int status[2];
+    double seq;             // sequence number of the step that wrote the block (host checks it against the one it sent)
 };
 struct VgMspace {
     // inputs

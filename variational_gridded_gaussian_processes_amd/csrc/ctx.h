@@ -70,6 +70,7 @@ struct vggp_ctx {
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start
     int sub_r_cap[2] = {0, 0};        // ranks the _S graphs were captured with
     bool sub_mode = false;            // the current step uses the subspace start (U then holds the identity)         // the last step ended in the polish in both dimensions: refine the next start basis
+    long seq = 0;                     // step sequence number (h_theta[5] -> device theta[5] -> VgHostOut::seq)
     int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
     bool prof = false;

@@ -695,7 +695,7 @@ __device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, do
                 pw = __hip_atomic_load(&J.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int avail = (pw & (VG_EIG_DONE - 1)) - consumed;
                 if ((pw & VG_EIG_DONE) || avail >= rounds_per_chunk || avail >= 8) break;      // small batches: short tail after DONE
-                if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; break; }   // bounded spin: never hang the GPU
+                if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; if (J.err) atomicOr(J.err, 1); break; }   // bounded spin: never hang the GPU
                 __builtin_amdgcn_s_sleep(8);
             }
             s_sync[0] = pw;
@@ -1224,7 +1224,7 @@ __device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int*
             for (;;) {
                 pw = __hip_atomic_load(&J.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((pw & VG_EIG_DONE) || (pw & (VG_EIG_DONE - 1)) > consumed) break;
-                if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; break; }
+                if (++spins > (1 << 24)) { pw = VG_EIG_DONE | 0x20000000; if (J.err) atomicOr(J.err, 1); break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             s_sync[0] = pw;
@@ -1280,7 +1280,9 @@ __device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int*
 
 // One launch, two roles: blockIdx.x == 0 is the Jacobi producer of matrix blockIdx.y, blockIdx.x >= 1 replay its
 // rotation log on column block blockIdx.x-1 of Q^T while the producer is still running (the replay is ~3x faster
-// per round, so it finishes a few microseconds after the producer).  At most 2*(1+8) workgroups: always co-resident.
+// per round, so it finishes a few microseconds after the producer).  At most 2*(1+16) workgroups of up to 1024 threads / 136 KB LDS:
+// co-resident on an otherwise idle MI355X, NOT guaranteed on a shared GPU -- hence the bounded spin of the replay
+// workgroups and the error word (VgEigJob::err) they raise on a timeout (surfaces as VGGP_ENOCONV).
 __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     extern __shared__ __attribute__((aligned(16))) double vg_eig_dyn[];   // double2 views of it are read with ds_read_b128
     __shared__ double2 cs[512];

@@ -187,10 +187,16 @@ __device__ void vg_final_body(const VgMspace& ms, VgFinPre& P, double* red, doub
             const int k = (threadIdx.x - 32) >> 2, q = (threadIdx.x - 32) & 3;
             ired[k * 4 + q] = ms.counters[k] ? ms.counters[k][q] : 0;
         }
-        if (threadIdx.x >= 64 && threadIdx.x < 66) ired[8 + threadIdx.x - 64] = ms.status[threadIdx.x - 64] ? *ms.status[threadIdx.x - 64] : 0;
+        if (threadIdx.x >= 64 && threadIdx.x < 66) {
+            // status word of the dimension: Cholesky status, else the eigensolver's replay-timeout flag (word 1)
+            const int* sp = ms.status[threadIdx.x - 64];
+            const int s0 = sp ? sp[0] : 0, s1 = sp ? sp[1] : 0;
+            ired[8 + threadIdx.x - 64] = s0 ? s0 : (s1 ? VGGP_ENOCONV : 0);
+        }
+        if (threadIdx.x == 66) stage[15] = ms.theta[5];          // the step's sequence number travels back with the results
         __syncthreads();
-        static_assert(sizeof(VgHostOut) == 15 * 8, "VgHostOut layout");
-        if (threadIdx.x < 15) reinterpret_cast<double*>(ms.hout)[threadIdx.x] = stage[threadIdx.x];
+        static_assert(sizeof(VgHostOut) == 16 * 8, "VgHostOut layout");
+        if (threadIdx.x < 16) reinterpret_cast<double*>(ms.hout)[threadIdx.x] = stage[threadIdx.x];
     }
 }
 
