@@ -64,14 +64,16 @@ def theta_from_raw(raw):
     return th
 
 
+PROJ = "gemm_project(S=[B2;V2]Y)"
+
+
 def algorithmic_flops(n1, n2, m1, m2):
     """Per-rank flops of one step by launch group (dense-contraction counts)."""
     f = {}
-    f["gemm_BV(Linv*[A|dA])"] = 2 * (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2) + 2 * (m1 ** 3 + m2 ** 3)
-    f["gemm_gram+project(S=[B2;V2]Y)"] = 2 * 2 * m2 * n1 * n2                 # S = [B2;V2] Y  (the only pass over Y)
-    f["gemm_C(B1*S)"] = (2 * 3 * m1 * m2 * n1                               # [C;C1;C2]
-                         + 2 * (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2)           # [G;H] = [B;V] B^T, both dimensions
-                         + 2 * (m1 ** 3 + m2 ** 3))                            # Mk
+    f["trsm_BV(L^-1[A|dA|dK])"] = (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2) + (m1 ** 3 + m2 ** 3)     # substitution: m^2 per column
+    f[PROJ] = 2 * 2 * m2 * n1 * n2                                                # S = [B2;V2] Y  (the only pass over Y)
+    f["gemm_C(B1*S)"] = 2 * 3 * m1 * m2 * n1                                       # [C;C1;C2]
+    f["gemm_gram(G,H,Mk)"] = 2 * (2 * m1 * m1 * n1 + 2 * m2 * m2 * n2) + 2 * (m1 ** 3 + m2 ** 3)
     f["gemm_rotate_right"] = 2 * 2 * (m1 ** 3 + m2 ** 3) + 2 * 3 * m1 * m2 * m2
     f["gemm_rotate_left"] = 2 * 2 * (m1 ** 3 + m2 ** 3) + 2 * 3 * m1 * m1 * m2
     f["gemm_betaGram"] = 2 * 2 * (m1 * m1 * m2 + m2 * m2 * m1)
@@ -133,7 +135,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=1024, help="grid points per axis per rank")
+    ap.add_argument("--n", type=int, default=1024, help="grid points per axis per rank (shorthand for --n1 N --n2-local N)")
+    ap.add_argument("--n1", type=int, default=None, help="grid points along dimension 1 (the fast axis of Y; not sharded)")
+    ap.add_argument("--n2-local", type=int, default=None, help="grid rows (dimension 2) per rank: BASELINE configs[3] is "
+                                                              "--gpus 4 --n1 4096 --n2-local 1024")
+    ap.add_argument("--no-extras", action="store_true", help="skip cold_ms_per_step / m_d_sweep / kron_solve")
     ap.add_argument("--m", type=int, default=128, help="inducing points per dimension")
     ap.add_argument("--kind", default="rbf")
     ap.add_argument("--cold", action="store_true", help="disable the eigensolver warm start")
@@ -166,10 +172,13 @@ def main():
     from variational_gridded_gaussian_processes_amd import Engine
     from oracle import dense as D      # synthetic-data generator only (gen_2d layout + the notebooks' latent function)
 
-    n1, n2_loc, m = args.n, args.n, args.m
+    n1 = args.n1 if args.n1 is not None else args.n
+    n2_loc = args.n2_local if args.n2_local is not None else args.n
+    m = args.m
     n2_glob = n2_loc * world
     # global grid: x1 in [0,1] (n1 points), x2 in [0, world] (n2_loc*world points, same spacing per slab)
     X, y, x1, x2 = D.gen_grid(n1, n2_glob, lims2=(0.0, float(world)), seed=0)
+    del X
     Yg = y.reshape(n2_glob, n1)
     sl = slice(rank * n2_loc, (rank + 1) * n2_loc)
     g1 = np.linspace(0, 1, m)
@@ -230,7 +239,7 @@ def main():
     if rank == 0:
         flops = algorithmic_flops(n1, n2_loc, m, m)
         dom = max(stages_us, key=stages_us.get)
-        proj = "gemm_gram+project(S=[B2;V2]Y)"
+        proj = PROJ
         proj_tflops = flops[proj] / (stages_us[proj] * 1e-6) / 1e12
         step_flops = sum(flops.values())
         roofline = {
@@ -286,26 +295,31 @@ def pmc_traffic():
 
 
 def kron_solve_bench(eng, n, reps=20):
+    """BASELINE metric (ii): X = K1^{-1} Y K2^{-T} FROM THE CHOLESKY FACTORS (nothing pre-inverted: the whole solve --
+    diagonal-block inverses, four blocked triangular solves -- is inside the timed region).  Algorithmic bytes and flops as
+    SURVEY.md section 8d defines them: 16 n1 n2 + 4 (n1^2 + n2^2) bytes, 2 n1^2 n2 + 2 n2^2 n1 flops (four triangular solves)."""
     import torch
     from oracle import kron as Kr
     z = np.linspace(0, 1, n)
     K1, _ = Kr.points_factor("matern12", z, z, 0.2)
     K2, _ = Kr.points_factor("matern32", z, z, 0.05)
-    _, L1i, _ = eng.cholesky_inverse(torch.tensor(K1, device=eng.device))
-    _, L2i, _ = eng.cholesky_inverse(torch.tensor(K2, device=eng.device))
+    L1, _, _ = eng.cholesky_inverse(torch.tensor(K1, device=eng.device))
+    L2, _, _ = eng.cholesky_inverse(torch.tensor(K2, device=eng.device))
     Yk = torch.randn(n, n, dtype=torch.float64, device=eng.device)
     for _ in range(3):
-        eng.kron_solve(L1i, L2i, Yk)
+        eng.kron_solve(L1, L2, Yk)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        Xk = eng.kron_solve(L1i, L2i, Yk)
+        Xk = eng.kron_solve(L1, L2, Yk)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     resid = float((torch.tensor(K1, device=eng.device) @ Xk @ torch.tensor(K2, device=eng.device).T - Yk).abs().max())
     alg_bytes = 16 * n * n + 4 * (n * n + n * n)
+    flops = 4 * n ** 3
     return {"n": n, "ms": dt * 1e3, "GB/s": alg_bytes / dt / 1e9, "algorithmic_bytes": alg_bytes,
-            "TFLOP/s_algorithmic(4n^3)": 4 * n ** 3 / dt / 1e12, "max_abs_residual": resid}
+            "TFLOP/s_algorithmic(4n^3)": flops / dt / 1e12, "frac_of_fp64_peak": flops / dt / 1e12 / FP64_PEAK_TFLOPS,
+            "from": "Cholesky factors (substitution; no factor is inverted)", "max_abs_residual": resid}
 
 
 if __name__ == "__main__":

@@ -199,17 +199,23 @@ int vggp_gemm(vggp_ctx* ctx, const double* A, int64_t sa_m, int64_t sa_k,
               const double* B, int64_t sb_k, int64_t sb_n,
               double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
 
-/* Kronecker solve  X = K1^{-1} Y K2^{-T}  from Cholesky factors, applied as
- * L^{-T}(L^{-1} .) on each side without materialising K1 (x) K2 (BASELINE metric ii).
- * L1inv [n1][n1], L2inv [n2][n2] (from vggp_cholesky_inverse), Y, X DEVICE [n1][n2].
- * Replaces Kuu.inv_matmul(.) with Kuu = torch.kron(Kuu_1, Kuu_2) (kronecker_structure.py:269, :805). */
-int vggp_kron_solve(vggp_ctx* ctx, const double* L1inv, int64_t n1, const double* L2inv, int64_t n2,
+/* Triangular solve by substitution on the matrix cores: L X = R (trans = 0) or L^T X = R (trans = 1), L DEVICE [m][m]
+ * lower-triangular (row-major, the upper part is not read), R, X DEVICE [m][ncols] row-major (X may alias R).
+ * Blocked: 16 x 16 diagonal blocks inverted in a wave, 128 x 128 diagonal blocks solved from LDS, the rest by MFMA GEMM
+ * updates (csrc/trsm.hip).  Replaces the triangular solves inside lazify(Kuu).inv_matmul (kronecker_structure.py:269). */
+int vggp_trsm(vggp_ctx* ctx, const double* L, int64_t m, const double* R, int64_t ncols, double* X, int trans, void* stream);
+
+/* Kronecker solve  X = K1^{-1} Y K2^{-T},  K_d = L_d L_d^T,  from the CHOLESKY FACTORS (BASELINE metric ii): four
+ * triangular solves by substitution, X = L1^{-T} (L1^{-1} Y L2^{-T}) L2^{-1}, never materialising K1 (x) K2 nor an inverse
+ * of a factor.  L1 [n1][n1], L2 [n2][n2] lower-triangular (e.g. from vggp_cholesky_inverse), Y, X DEVICE [n1][n2]
+ * (X may alias Y).  Replaces Kuu.inv_matmul(.) with Kuu = torch.kron(Kuu_1, Kuu_2) (kronecker_structure.py:269, :805). */
+int vggp_kron_solve(vggp_ctx* ctx, const double* L1, int64_t n1, const double* L2, int64_t n2,
                     const double* Y, double* X, void* stream);
 
 /* Per-stage timing with HIP events on the stream the kernels are launched on (bench.py's
  * live roofline measurement).  When enabled, every ELBO step records one event after each
  * launch group; vggp_profile_read returns the accumulated milliseconds per stage. */
-#define VGGP_NSTAGE 14
+#define VGGP_NSTAGE 20
 int         vggp_profile(vggp_ctx* ctx, int enable);
 int         vggp_profile_read(vggp_ctx* ctx, double ms_out[VGGP_NSTAGE], int32_t* steps_out, int reset);
 const char* vggp_stage_name(int stage);

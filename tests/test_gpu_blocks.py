@@ -121,18 +121,59 @@ def test_eigh(engine, m, kind, block):
         assert np.all(np.diff(lam) <= 0)
 
 
-def test_kron_solve(engine):
-    n1, n2 = 96, 130
-    K1, _ = Kr.points_factor("matern32", np.linspace(0, 1, n1), np.linspace(0, 1, n1), 0.1)
-    K2, _ = Kr.points_factor("matern12", np.linspace(0, 1, n2), np.linspace(0, 1, n2), 0.3)
-    Y = np.random.default_rng(0).standard_normal((n1, n2))
-    _, L1i, _ = engine.cholesky_inverse(torch.tensor(K1, device=DEV))
-    _, L2i, _ = engine.cholesky_inverse(torch.tensor(K2, device=DEV))
-    X = engine.kron_solve(L1i, L2i, torch.tensor(Y, device=DEV)).cpu().numpy()
-    ref = Kr.kron_solve(np.linalg.cholesky(K1), np.linalg.cholesky(K2), Y)
+@pytest.mark.parametrize("trans", [False, True], ids=["L", "Lt"])
+@pytest.mark.parametrize("m,kind,ell", [(7, "matern12", 0.3), (64, "rbf", 0.2), (128, "rbf", 0.2), (130, "matern32", 0.2),
+                                        (256, "matern52", 0.1), (300, "matern12", 0.2), (1024, "matern32", 0.05)])
+def test_trsm_vs_scipy(engine, m, kind, ell, trans):
+    """vggp_trsm (substitution on the matrix cores: strip kernel for the 128 x 128 diagonal blocks, MFMA GEMM updates
+    between them) against scipy.linalg.solve_triangular, both orientations, ragged sizes, ill-conditioned RBF factors."""
+    import scipy.linalg as sla
+    z = np.linspace(0, 1, m)
+    K, _ = Kr.points_factor(kind, z, z, ell)
+    L, _ = Kr.chol_jitter(K)
+    R = np.random.default_rng(m).standard_normal((m, 77))
+    ref = sla.solve_triangular(L, R, lower=True, trans="T" if trans else "N")
+    X = engine.trsm(torch.tensor(L, device=DEV), torch.tensor(R, device=DEV), trans=trans).cpu().numpy()
+    # forward error relative to the solution scale (cond(L) up to 1e5 here) and the backward-stable residual
     assert rel(X, ref) < 1e-9
-    # size-independent property: K1 X K2^T == Y
-    assert rel(K1 @ X @ K2.T, Y) < 1e-9
+    resid = (L.T if trans else L) @ X - R
+    assert np.abs(resid).max() < 1e-10 * max(1.0, np.abs(L).max() * np.abs(X).max())
+
+
+def test_trsm_in_place_and_wide(engine):
+    """ncols not a multiple of the 64-column workgroup tile, X aliasing R."""
+    import scipy.linalg as sla
+    m, ncols = 96, 1000
+    z = np.linspace(0, 1, m)
+    K, _ = Kr.points_factor("matern32", z, z, 0.15)
+    L = np.linalg.cholesky(K)
+    R = np.random.default_rng(1).standard_normal((m, ncols))
+    Rt = torch.tensor(R, device=DEV)
+    from variational_gridded_gaussian_processes_amd._lib import check
+    check(engine.lib.vggp_trsm(engine._h, torch.tensor(L, device=DEV).data_ptr(), m, Rt.data_ptr(), ncols, Rt.data_ptr(), 0, 0))
+    torch.cuda.synchronize()
+    assert rel(Rt.cpu().numpy(), sla.solve_triangular(L, R, lower=True)) < 1e-11
+
+
+@pytest.mark.parametrize("n1,n2", [(96, 130), (1024, 1024)])
+def test_kron_solve(engine, n1, n2):
+    """BASELINE metric (ii) from the CHOLESKY FACTORS: X = K1^{-1} Y K2^{-T} by four triangular solves, against the CPU oracle
+    (scipy.linalg.solve_triangular, oracle/kron.py kron_solve) and the size-independent residual K1 X K2^T == Y."""
+    K1, _ = Kr.points_factor("matern32", np.linspace(0, 1, n1), np.linspace(0, 1, n1), 0.1 if n1 < 500 else 0.05)
+    K2, _ = Kr.points_factor("matern12", np.linspace(0, 1, n2), np.linspace(0, 1, n2), 0.3 if n2 < 500 else 0.2)
+    Y = np.random.default_rng(0).standard_normal((n1, n2))
+    L1, L2 = np.linalg.cholesky(K1), np.linalg.cholesky(K2)
+    X = engine.kron_solve(torch.tensor(L1, device=DEV), torch.tensor(L2, device=DEV), torch.tensor(Y, device=DEV)).cpu().numpy()
+    ref = Kr.kron_solve(L1, L2, Y)
+    assert rel(X, ref) < 1e-9
+    # size-independent property: K1 X K2^T == Y, to the residual a backward-stable solve leaves (eps cond |Y|)
+    r_gpu, r_ref = np.abs(K1 @ X @ K2.T - Y).max(), np.abs(K1 @ ref @ K2.T - Y).max()
+    assert r_gpu < 1e-9 * np.abs(X).max() and r_gpu < 20 * max(r_ref, 1e-12)
+    # factors straight from the engine's own Cholesky
+    Lg1, _, _ = engine.cholesky_inverse(torch.tensor(K1, device=DEV))
+    Lg2, _, _ = engine.cholesky_inverse(torch.tensor(K2, device=DEV))
+    X2 = engine.kron_solve(Lg1, Lg2, torch.tensor(Y, device=DEV)).cpu().numpy()
+    assert rel(X2, ref) < 1e-8
 
 
 def test_sumsq(engine):

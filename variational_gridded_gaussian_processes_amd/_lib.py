@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(HERE, "libvggp_hip.so")
 
 VGGP_OK, VGGP_EINVAL, VGGP_ENOTPD, VGGP_EHIP, VGGP_ENOMEM, VGGP_ESTATE, VGGP_ENOCONV = 0, -1, -2, -3, -4, -5, -6
 KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
-NSTAGE = 14
+NSTAGE = 20
 FLAG_B0_F32_KDELTA = 1
 FLAG_BLOCK_JACOBI = 2
 BASIS = {"points": 0, "b0": 1, "one": 2, "vff": 3, "b1": 4}
@@ -62,6 +62,7 @@ SYMBOLS = {
     "vggp_eigh": (_I, [_P, _P, _I64, _P, _P, C.POINTER(C.c_int32), _I, _P]),
     "vggp_gemm": (_I, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "vggp_kron_solve": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
+    "vggp_trsm": (_I, [_P, _P, _I64, _P, _I64, _P, _I, _P]),
     "vggp_sumsq": (_I, [_P, _P, _I64, C.POINTER(_D), _P]),
     "vggp_profile": (_I, [_P, _I]),
     "vggp_profile_read": (_I, [_P, C.POINTER(_D), C.POINTER(C.c_int32), _I]),

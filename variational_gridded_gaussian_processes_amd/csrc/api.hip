@@ -29,16 +29,34 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 static void graphs_clear(vggp_ctx* c);
 
 static const char* VG_STAGE_NAMES[VGGP_NSTAGE] = {
-    "factor_build", "cholesky_inverse", "gemm_BV(Linv*[A|dA])", "gemm_gram+project(S=[B2;V2]Y)", "gemm_C(B1*S)",
-    "reduce_slabs", "gemm_warm_start", "jacobi_eigh+replay(fused)", "(unused)", "gemm_rotate_right", "gemm_rotate_left",
-    "dstage", "gemm_betaGram", "final_reduce"};
+    "factor_build", "cholesky_inverse", "trsm_BV(L^-1[A|dA|dK])", "extrap_basis(3 small gemms)", "gemm_project(S=[B2;V2]Y)",
+    "gemm_C(B1*S)", "gemm_gram(G,H,Mk)", "reduce_slabs", "warm_first_gemm([Z,G]|TM)", "rowqr|refine", "warm_mid_gemms",
+    "ritz_eigh", "warm_last_gemms(->Gw)", "jacobi_eigh+replay(fused)", "gemm_rotate_right", "gemm_rotate_left", "dstage",
+    "gemm_betaGram", "final_reduce", "(unused)"};
 extern "C" const char* vggp_stage_name(int i) { return (i >= 0 && i < VGGP_NSTAGE) ? VG_STAGE_NAMES[i] : ""; }
 
-// record event `slot` (slot 0 = start of partials, slot k = after stage k-1; slot 7 doubles as start of finish)
-#define VG_MARK(slot)                                                   \
-    do {                                                                \
-        if (c->prof) { VG_HIP(hipEventRecord(c->ev[slot], st)); c->ev_set[slot] = true; } \
+// Per-stage profiling (bench.py): in profiling mode the step runs as plain launches on ONE stream (no graph, no side stream)
+// and an event is recorded after every launch group; stage `id` is charged the time since the previous event.
+// VG_MARK(-1) only (re)starts the clock (start of the step, start of the finish half after the caller's all-reduce).
+#define VG_MARK(id)                                                                                     \
+    do {                                                                                                \
+        if (c->prof && c->nev < VG_MAXEV) { VG_HIP(hipEventRecord(c->ev[c->nev], st)); c->ev_stage[c->nev++] = (id); } \
     } while (0)
+
+// Fork / join onto the context's side stream (works eagerly and under stream capture, where it becomes a graph branch).
+// OFF by default: measured on ROCm 7.2 / MI355X (gpurun_out/r2c), running the projection of Y (2 launches, 40 us) beside
+// the eigensolver chain as a second graph branch made the 1024^2 step SLOWER (0.478 vs 0.453 ms) -- every cross-stream
+// edge of a replayed graph costs more than the launches it hides; independent work is batched into shared launches
+// instead (see the prediction GEMMs in the tail of finish_enqueue).  VGGP_FORK=1 switches the branch on for A/B runs.
+// Profiling mode keeps everything on the one stream so that the per-stage events mean what they say.
+static hipStream_t vg_side(vggp_ctx* c, hipStream_t st) {
+    static const bool on = getenv("VGGP_FORK") != nullptr;
+    return (c->prof || !on) ? st : c->side_stream;
+}
+#define VG_FORK(i)                                                                                      \
+    do { if (sx != st) { VG_HIP(hipEventRecord(c->ev_fork[i], st)); VG_HIP(hipStreamWaitEvent(sx, c->ev_fork[i], 0)); } } while (0)
+#define VG_JOIN_RECORD(i) do { if (sx != st) VG_HIP(hipEventRecord(c->ev_join[i], sx)); } while (0)
+#define VG_JOIN_WAIT(i) do { if (sx != st) VG_HIP(hipStreamWaitEvent(st, c->ev_join[i], 0)); } while (0)
 
 int vg_ensure_misc(vggp_ctx* c, size_t bytes) {
     if (c->misc_bytes >= bytes) return VGGP_OK;
@@ -62,12 +80,18 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
     }
     VG_HIP(vg_chol_setup());
     VG_HIP(vg_eigh_setup());
+    VG_HIP(vg_trsm_setup());
     vggp_ctx* c = new (std::nothrow) vggp_ctx();
     if (!c) { vg_set_error("out of host memory"); return VGGP_ENOMEM; }
     c->device = device;
     const char* ng = getenv("VGGP_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     VG_HIP(hipStreamCreate(&c->own_stream));
+    VG_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    for (int i = 0; i < VG_NFORK; ++i) {
+        VG_HIP(hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming));
+        VG_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
     VG_HIP(hipHostMalloc((void**)&c->h_theta, 8 * sizeof(double), hipHostMallocDefault));
     VG_HIP(hipHostMalloc((void**)&c->h_out, sizeof(HostOut), hipHostMallocDefault));
     VG_HIP(hipHostGetDevicePointer((void**)&c->d_hout, c->h_out, 0));
@@ -85,7 +109,12 @@ extern "C" int vggp_destroy(vggp_ctx* c) {
     VgDeviceGuard guard;
     (void)guard.enter(c->device);
     for (int i = 0; i < 12; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
-    for (int i = 0; i < VGGP_NSTAGE + 2; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < VG_MAXEV; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < VG_NFORK; ++i) {
+        if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     vg_masked_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->arena) (void)hipFree(c->arena);
@@ -183,6 +212,9 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.QtPrev = b.take<double>(m * m);
         d.QtPrev2 = b.take<double>(m * m);
         d.U = b.take<double>(m * m);
+        d.Ep = b.take<double>(m * m);
+        d.Fp = b.take<double>(m * m);
+        d.Wp = b.take<double>(m * m);
         d.Id = b.take<double>(m * m);
         d.Gw = b.take<double>(m * m);
         d.GH = b.take<double>(2 * m * m);
@@ -267,6 +299,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     c->warm_run = 0;
     c->refine_next = false;
     c->sub_next = false; c->sub_mode = false; c->sub_r_cap[0] = c->sub_r_cap[1] = 0;
+    c->pred_consumed = false;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -309,12 +342,69 @@ extern "C" int64_t vggp_payload_len(const vggp_ctx* c) { return (c && c->planned
 extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t)c->arena_used : 0; }
 
 // ---------------------------------------------------------------------------------
+// ---- triangular solves for any m: blocked substitution ------------------------------------------------------------------
+// A batch of solves, each in place on its X (element (row k, column c) at X[k * sk + c * sc], one of the two strides is 1).
+// m <= 128: one launch of the strip kernel (trsm.hip).  Larger m: block rows of VG_TRSM_BLK = 128; per block row ONE MFMA
+// GEMM launch subtracts the contribution of the block rows already solved (L[b, :b] X[:b], all workgroups of the chip, all
+// jobs of the batch) and ONE strip-kernel launch solves the 128 x 128 diagonal blocks (factor staged in LDS).
+// Dinv: inverses of the 16 x 16 diagonal blocks of L, block b16 at Dinv + b16 * dinv_blk, row stride dinv_ld.
+#define VG_TRSM_BLK 128
+struct VgTrsmSpec {
+    const double* L; long ldl;
+    const double* Dinv; long dinv_blk, dinv_ld;
+    double* X; long sk, sc, ncols;
+    long m; int trans;
+};
+static int trsm_batch(const VgTrsmSpec* sp, int n, hipStream_t st) {
+    int max_nblk = 0;
+    for (int j = 0; j < n; ++j) max_nblk = std::max(max_nblk, (int)((sp[j].m + VG_TRSM_BLK - 1) / VG_TRSM_BLK));
+    for (int s = 0; s < max_nblk; ++s) {
+        VgGemmBatch g;
+        vg_gemm_init(&g);
+        VgTrsmJob tj[12];
+        int nt = 0;
+        for (int j = 0; j < n; ++j) {
+            const VgTrsmSpec& q = sp[j];
+            const int nblk = (int)((q.m + VG_TRSM_BLK - 1) / VG_TRSM_BLK);
+            if (s >= nblk) continue;
+            const int b = q.trans ? nblk - 1 - s : s;
+            const long r0 = (long)b * VG_TRSM_BLK, rb = std::min<long>(VG_TRSM_BLK, q.m - r0), r1 = r0 + rb;
+            // rows of X already solved: [0, r0) for L X = R, [r1, m) for L^T X = R
+            const long k0 = q.trans ? r1 : 0, kn = q.trans ? q.m - r1 : r0;
+            if (kn > 0) {
+                // operator block T (rb x kn): T[i][k] = L[r0 + i][k0 + k] (no trans) or L[k0 + k][r0 + i] (trans)
+                const double* Tp = q.trans ? q.L + k0 * q.ldl + r0 : q.L + r0 * q.ldl + k0;
+                const long t_i = q.trans ? 1 : q.ldl, t_k = q.trans ? q.ldl : 1;
+                if (q.sc == 1)        // X row-major: X[r0:r1, :] -= T X[k0:k0+kn, :]
+                    vg_gemm_add(&g, Tp, t_i, t_k, q.X + k0 * q.sk, q.sk, 1, q.X + r0 * q.sk, (int)q.sk, (int)rb, (int)q.ncols, (int)kn,
+                                1, 0, 1, 0, -1.0, 1);
+                else                  // X holds the transposed right-hand sides: X'[:, r0:r1] -= X'[:, k0:k0+kn] T^T
+                    vg_gemm_add(&g, q.X + k0, q.sc, 1, Tp, t_k, t_i, q.X + r0, (int)q.sc, (int)q.ncols, (int)rb, (int)kn, 1, 0, 1, 0,
+                                -1.0, 1);
+            }
+            if (nt >= 12) { vg_set_error("trsm_batch: too many jobs"); return VGGP_EINVAL; }
+            tj[nt++] = VgTrsmJob{q.L + r0 * q.ldl + r0, q.Dinv + (r0 / 16) * q.dinv_blk, q.X + r0 * q.sk, q.X + r0 * q.sk, q.ldl,
+                                 q.dinv_blk, q.dinv_ld, q.sk, q.sc, q.sk, q.sc, q.ncols, (int)rb, q.trans};
+        }
+        if (g.nprob) VG_HIP(vg_gemm_launch(&g, st));
+        if (nt) VG_HIP(vg_trsm_launch(tj, nt, st));
+    }
+    return VGGP_OK;
+}
+static int trsm_inplace(const double* L, long m, long ldl, const double* Dinv, double* X, long x_sk, long x_sc, long ncols,
+                        int trans, hipStream_t st) {
+    VgTrsmSpec q{L, ldl, Dinv, 256, 16, X, x_sk, x_sc, ncols, m, trans};
+    return trsm_batch(&q, 1, st);
+}
+
 // Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
 // caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap) {
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap, bool fused, bool apply_ns) {
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
-    VG_MARK(0);
+    hipStream_t sx = vg_side(c, st);
+    VgGemmBatch g;
+    VG_MARK(-1);
 
     // 1. factor build (unit outputscale): A0|dA0, K0, dK0 for both dimensions.  First node of the step: it reads the
     //    hyper-parameters from the pinned host block (and leaves a device copy for the later kernels), and its block 0
@@ -332,53 +422,63 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
     }
     VG_HIP(vg_factor_build_launch(fj, 2, c->d_htheta, st, c->theta, &clr));
-    VG_MARK(1);
+    VG_MARK(0);
 
     // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
     VG_HIP(vg_chol_launch(cj, 2, st));
+    VG_MARK(1);
+
+    // 3. B|V = L0^{-1} [A0|dA0],  X = L0^{-1} dK0  by blocked substitution on the matrix cores (trsm.hip; the 16 x 16
+    //    diagonal-block inverses are the diagonal blocks of Linv0).  Not "Linv0 times A0": on RBF factors that product
+    //    carries cond(L0) into every element of B and shows in the posterior variance of large grids.
+    {
+        const bool big = d1.m > VG_TRSM_BLK || d2.m > VG_TRSM_BLK;
+        if (!big) {
+            VgTrsmJob tj[6];
+            int nt = 0;
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                const long mn = (long)d.m * d.n;
+                for (int b = 0; b < 2; ++b)
+                    tj[nt++] = VgTrsmJob{d.L0, d.Linv0, d.AD + b * mn, d.BV + b * mn, d.m, 16L * d.m + 16, d.m, d.n, 1, d.n, 1, d.n, d.m, 0};
+                tj[nt++] = VgTrsmJob{d.L0, d.Linv0, d.dK0, d.X, d.m, 16L * d.m + 16, d.m, d.m, 1, d.m, 1, d.m, d.m, 0};
+            }
+            VG_HIP(vg_trsm_launch(tj, nt, st));
+        } else {
+            // 128 < m <= 256: blocked (128-row diagonal solves + one GEMM update between them), in place on copies
+            VgTrsmSpec q[6];
+            int nq = 0;
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                const long mn = (long)d.m * d.n;
+                VG_HIP(hipMemcpyAsync(d.BV, d.AD, sizeof(double) * 2 * mn, hipMemcpyDeviceToDevice, st));
+                VG_HIP(hipMemcpyAsync(d.X, d.dK0, sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
+                for (int b = 0; b < 2; ++b) q[nq++] = VgTrsmSpec{d.L0, d.m, d.Linv0, 16L * d.m + 16, d.m, d.BV + b * mn, d.n, 1, d.n, d.m, 0};
+                q[nq++] = VgTrsmSpec{d.L0, d.m, d.Linv0, 16L * d.m + 16, d.m, d.X, d.m, 1, d.m, d.m, 0};
+            }
+            const int rc = trsm_batch(q, nq, st);
+            if (rc) return rc;
+        }
+    }
     VG_MARK(2);
 
-    // 3. B|V = Linv0 [A0|dA0],  X = Linv0 dK0
-    VgGemmBatch g;
-    vg_gemm_init(&g);
-    for (int k = 0; k < 2; ++k) {
-        VgDim& d = c->d[k];
-        const long mn = (long)d.m * d.n;
-        for (int b = 0; b < 2; ++b)
-            vg_gemm_add(&g, d.Linv0, d.m, 1, d.AD + b * mn, d.n, 1, d.BV + b * mn, d.n, d.m, d.n, d.m);
-        vg_gemm_add(&g, d.Linv0, d.m, 1, d.dK0, d.m, 1, d.X, d.m, d.m, d.m, d.m);
-    }
-    // extrapolated warm start, riding in launches that exist anyway: the basis moved from Q(t-2) to Q(t-1) by the rotation
-    // U = Q(t-1) Q(t-2)^T (formed in the LAST launch group of the previous step); applying it once more predicts this
-    // step's basis, Qpred = U Q(t-1) (rows = eigenvectors; Qpred -> E, 1.5 Qpred -> F, free until after eigh).
-    // A product of three bases triples their departure from orthogonality and feeds it back into the next bases -- it
-    // would grow ~2.4x per step -- so one Newton-Schulz step follows: Q' = 1.5 Qpred - 0.5 (Qpred Qpred^T) Qpred
-    // (W = Qpred Qpred^T -> TH in the next launch, F += -0.5 W Qpred in the one after).
-    if (extrap)
-        for (int k = 0; k < 2; ++k) {
-            VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.U, d.m, 1, d.QtPrev, d.m, 1, d.E, d.m, d.m, d.m, d.m);
-            vg_gemm_add(&g, d.U, d.m, 1, d.QtPrev, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 1.5, 0);
-        }
-    VG_HIP(vg_gemm_launch(&g, st));
-    VG_MARK(3);
-
-    // 4. S = [B2;V2] Y (split-K slabs): the only pass over Y.  Exactly tiles x splits = one workgroup per CU at the
-    //    headline size, so the Gram pairs that used to share this launch now ride in the next one (whose own products
-    //    fill less than half the chip): two workgroups on one CU halve each other's MFMA rate.
+    // 4./5. (side stream in the fused step: overlaps the Gram products and the whole eigensolver chain, which need only G, H)
+    //    S = [B2;V2] Y (split-K slabs): the only pass over Y; then [C;C1] = [B1;V1] S_B, C2 = B1 S_V (S slabs summed on
+    //    load; split-K over n1).
+    hipStream_t sp = (fused && !extrap) ? sx : st;
+    if (sp != st) VG_FORK(1);
     vg_gemm_init(&g);
     vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
     const int st_slabs = g.p[0].ksplit;
-    if (extrap)
+    // predicted start basis of this step's eigensolvers: the previous step's tail left Qpred (Ep), 1.5 Qpred (Fp) and
+    // W = Qpred Qpred^T (Wp); the Newton-Schulz step Fp += -0.5 W Qpred rides in this launch (see the tail of finish_enqueue)
+    if (extrap && apply_ns)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.E, d.m, 1, d.E, 1, d.m, d.TH, d.m, d.m, d.m, d.m);      // W = Qpred Qpred^T
+            vg_gemm_add(&g, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
         }
-    VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_GRAM_PROJECT));
-    VG_MARK(4);
-
-    // 5. [C;C1] = [B1;V1] S_B,  C2 = B1 S_V   (S slabs summed on load; split-K over n1),
-    //    Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T
+    VG_HIP(vg_gemm_launch(&g, sp, VG_GEMM_TAG_GRAM_PROJECT));
+    if (sp == st) VG_MARK(4);
     vg_gemm_init(&g);
     const long cc_slab = 3L * m1 * m2;
     vg_gemm_add(&g, d1.BV, n1, 1, c->St, 1, n1, c->CCslab, (int)m2, (int)(2 * m1), (int)m2, (int)n1, c->cc_split, cc_slab,
@@ -386,6 +486,12 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
                 c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
     const int cc_slabs = g.p[0].ksplit;
+    VG_HIP(vg_gemm_launch(&g, sp));
+    if (sp == st) VG_MARK(5);
+    if (sp != st) VG_JOIN_RECORD(1);
+
+    // 6. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T
+    vg_gemm_init(&g);
     int gh_slabs[2] = {1, 1};
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
@@ -393,25 +499,21 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         gh_slabs[k] = g.p[ig].ksplit;
         vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
     }
-    if (extrap)
-        for (int k = 0; k < 2; ++k) {
-            VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.TH, d.m, 1, d.E, d.m, 1, d.F, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);   // Newton-Schulz
-        }
     VG_HIP(vg_gemm_launch(&g, st));
-    VG_MARK(5);
+    VG_MARK(6);
 
     c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs;
-    // 6. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}.  Skipped inside a fused
+    // 7. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}.  Skipped inside a fused
     //    warm step: its consumers (three small GEMMs) then sum the slabs on load, one launch less on the critical path.
-    if (!reduce) { VG_MARK(6); return VGGP_OK; }
+    if (!reduce) return VGGP_OK;          // fused warm step: the caller joins the projection branch before the rotations
+    if (sp != st) VG_JOIN_WAIT(1);
     VgRedBatch r;
     vg_red_init(&r);
     vg_red_add(&r, d1.GHslab, d1.GH, 2L * m1 * m1, 2L * m1 * m1, gh_slabs[0]);
     vg_red_add(&r, d2.GHslab, payload, 2L * m2 * m2, 2L * m2 * m2, gh_slabs[1]);
     vg_red_add(&r, c->CCslab, payload + 2 * m2 * m2, 3L * m1 * m2, cc_slab, cc_slabs);
     VG_HIP(vg_red_launch(&r, st));
-    VG_MARK(6);
+    VG_MARK(7);
     return VGGP_OK;
 }
 
@@ -438,12 +540,13 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     VgGemmBatch g;
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
-    VG_MARK(VGGP_NSTAGE + 1);     // start of finish (the all-reduce sits between slot 6 and this one)
+    hipStream_t sx = vg_side(c, st);
+    VG_MARK(-1);                  // (re)start the stage clock: the caller's all-reduce sits between the two halves
     const double* Hr[2] = {H0[0], H0[1]};      // H for the rotation below: a reduced copy when a warm chain's first launch made one
     int hrn[2] = {ghn[0], ghn[1]};
     VgEigJob ej[2];
     if (warm && subspace) {
-        // ---- subspace start (numerically rank-deficient G, e.g. RBF: rank ~20 of 128).  S = d.F is the previous basis after
+        // ---- subspace start (numerically rank-deficient G, e.g. RBF: rank ~20 of 128).  S = d.Fp is the previous basis after
         // one Newton-Schulz step (partials ran with U = I), rows sorted by decreasing eigenvalue; its r leading rows V span
         // the previous numerical range.  One step of subspace iteration, Z = V G, removes every null-space component
         // exactly (G annihilates them); V1 = orth(Z); Rayleigh-Ritz on H = V1 G V1^T gives the r leading eigenpairs;
@@ -459,27 +562,29 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.F, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);        // Z = V G
+            vg_gemm_add(&g, d.Fp, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);       // Z = V G
             if (from_slabs && ghn[k] > 1) {
                 vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
                 vg_gemm_add(&g, d.Id, d.m, 1, H0[k], d.m, 1, gdst[k] + (long)d.m * d.m, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
             }
         }
         VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(8);
         for (int k = 0; k < 2; ++k)
             if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; Hr[k] = gdst[k] + (long)c->d[k].m * c->d[k].m; hrn[k] = 1; }
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
-            qj[k] = VgRowQrJob{d.Zs, d.V1s, d.sub_r, d.m, d.F + r * d.m, d.E + r * d.m, (long)(d.m - r) * d.m};   // + E[r:] <- S[r:]
+            qj[k] = VgRowQrJob{d.Zs, d.V1s, d.sub_r, d.m, d.Fp + r * d.m, d.E + r * d.m, (long)(d.m - r) * d.m};   // + E[r:] <- S[r:]
         }
         VG_HIP(vg_rowqr_launch(qj, 2, st));
+        VG_MARK(9);
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
             vg_gemm_add(&g, d.V1s, d.m, 1, Gr[k], d.m, 1, d.Zs, d.m, (int)r, d.m, d.m, 1, 0, grn[k], ghs[k]);        // T = V1 G (Z is spent)
-            vg_gemm_add(&g, d.F + r * d.m, d.m, 1, d.V1s, 1, d.m, d.TH, (int)r, (int)(d.m - r), (int)r, d.m);           // P = S[r:] V1^T
+            vg_gemm_add(&g, d.Fp + r * d.m, d.m, 1, d.V1s, 1, d.m, d.TH, (int)r, (int)(d.m - r), (int)r, d.m);           // P = S[r:] V1^T
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);
@@ -490,6 +595,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_add(&g, d.TH, r, 1, d.V1s, d.m, 1, d.E + r * d.m, d.m, (int)(d.m - r), d.m, (int)r, 1, 0, 1, 0, -1.0, 1);   // E[r:] -= P V1
         }
         VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(10);
         VgEigJob sj[2];
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
@@ -499,6 +605,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             sj[k].err = d.status + 1;
         }
         VG_HIP(vg_eigh_launch(sj, 2, st));                                                                           // Ritz pairs
+        VG_MARK(11);
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
@@ -522,7 +629,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, extrap ? d.F : d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            vg_gemm_add(&g, extrap ? d.Fp : d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
             if (from_slabs && ghn[k] > 1) {                  // reduced copies for the later readers (G after a refinement, H in the rotation)
                 if (refine) {
                     vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
@@ -533,12 +640,14 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             }
         }
         VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(8);
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.TM, d.m, 1, extrap ? d.F : d.QtPrev, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.TM, d.m, 1, extrap ? d.Fp : d.QtPrev, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
         }
         VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(12);
         // First-order refinement of the start basis (used while the previous step ended in the polish, i.e. on
         // well-separated spectra): S' = (I + E + E^2/2) S with E from Gw = S G S^T, then Gw' = S' G S'^T.  Five short
         // launches that replace the one dense Jacobi sweep (127 rounds) the polish still needed: the eigensolver
@@ -548,10 +657,11 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             VgRefineJob rj[2];
             for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, 0.0}; }
             VG_HIP(vg_refine_launch(rj, 2, st));                                        // E -> U, I + E -> TH
+            VG_MARK(9);
             vg_gemm_init(&g);
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
-                const double* S0 = extrap ? d.F : d.QtPrev;
+                const double* S0 = extrap ? d.Fp : d.QtPrev;
                 vg_gemm_add(&g, d.TH, d.m, 1, S0, d.m, 1, d.E, d.m, d.m, d.m, d.m);    // (I + E) S -> E
                 vg_gemm_add(&g, d.U, d.m, 1, d.U, d.m, 1, d.X, d.m, d.m, d.m, d.m);     // E E -> X
             }
@@ -559,7 +669,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_init(&g);
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
-                const double* S0 = extrap ? d.F : d.QtPrev;
+                const double* S0 = extrap ? d.Fp : d.QtPrev;
                 vg_gemm_add(&g, d.X, d.m, 1, S0, d.m, 1, d.E, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 0.5, 1);   // += E^2 S / 2
             }
             VG_HIP(vg_gemm_launch(&g, st));
@@ -577,10 +687,10 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             VG_HIP(vg_gemm_launch(&g, st));
         }
     }
-    VG_MARK(7);
+    VG_MARK(12);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? ((refine || subspace) ? d.E : (extrap ? d.F : d.QtPrev)) : nullptr, d.gwork, d.rotlog, d.roundlog,
+        ej[k] = VgEigJob{warm ? d.Gw : G0[k], d.lam0, d.Qt, warm ? ((refine || subspace) ? d.E : (extrap ? d.Fp : d.QtPrev)) : nullptr, d.gwork, d.rotlog, d.roundlog,
                          d.counters, d.m, d.max_rounds, (long)vg_eigh_log_bytes(d.m),
                          (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) ? 1 : 0};
         ej[k].Qt2 = d.QtPrev;        // the replay workgroups leave the new basis in both places (next warm start, q(v))
@@ -591,8 +701,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         ej[k].sparse_first = (warm && subspace) ? 1 : 0;
     }
     VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
-    VG_MARK(8);
-    VG_MARK(9);
+    VG_MARK(13);
+    if (from_slabs) VG_JOIN_WAIT(1);          // fused step: the projection branch (S, C slabs) ran beside the eigensolver chain
 
     // 8. rotate into the eigenbasis: first the right factors ...
     vg_gemm_init(&g);
@@ -604,8 +714,23 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     }
     const int ic = vg_gemm_add(&g, C3, m2, 1, d2.Qt, 1, m2, c->T3, (int)m2, (int)(3 * m1), (int)m2, (int)m2);   // [C;C1;C2] Q2
     g.p[ic].a_nslab = ccn; g.p[ic].a_slab = ccs;
+    // Prediction of the NEXT step's start basis, riding in the three GEMM launches of this tail (and one of the next step's
+    // head): the basis moved from Q(t-1) to Q(t) by the rotation U = Q(t) Q(t-1)^T; applying it once more predicts the next
+    // basis, Qpred = U Q(t) (rows = eigenvectors).  A product of three bases triples their departure from orthogonality and
+    // feeds it back into the next bases -- it would grow ~2.4x per step -- so one Newton-Schulz step follows:
+    // Q' = 1.5 Qpred - 0.5 (Qpred Qpred^T) Qpred.  Here: U; next launch: Ep = Qpred, Fp = 1.5 Qpred; the beta-Gram launch:
+    // Wp = Qpred Qpred^T; the next step's projection launch: Fp += -0.5 Wp Ep.  The subspace start is fed the previous basis
+    // itself (U = I: only the Newton-Schulz clean-up), see vg_sub_ident().  (The eigensolver's replay workgroups have
+    // already left Q(t) in QtPrev and Q(t-1) in QtPrev2.)
+    const bool predict = c->desc.warm_start && !(c->desc.flags & VGGP_FLAG_BLOCK_JACOBI);
+    const bool pred_ident = c->sub_mode && vg_sub_ident();
+    if (predict && !pred_ident)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.U, d.m, d.m, d.m, d.m);
+        }
     VG_HIP(vg_gemm_launch(&g, st));
-    VG_MARK(10);
+    VG_MARK(14);
     //    ... then the left factors
     vg_gemm_init(&g);
     for (int k = 0; k < 2; ++k) {
@@ -615,8 +740,15 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     }
     for (int q = 0; q < 3; ++q)
         vg_gemm_add(&g, d1.Qt, m1, 1, c->T3 + q * m1 * m2, m2, 1, c->P3 + q * m1 * m2, (int)m2, (int)m1, (int)m2, (int)m1);
+    if (predict)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const double* Uk = pred_ident ? d.Id : d.U;
+            vg_gemm_add(&g, Uk, d.m, 1, d.QtPrev, d.m, 1, d.Ep, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, Uk, d.m, 1, d.QtPrev, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 1.5, 0);
+        }
     VG_HIP(vg_gemm_launch(&g, st));
-    VG_MARK(11);
+    VG_MARK(15);
 
     // 9. D-stage, the four beta Gram matrices, final reduction
     VgMspace ms;
@@ -630,21 +762,21 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     ms.ticket = c->ticket; ms.hout = c->d_hout;
     for (int k = 0; k < 2; ++k) { ms.jit[k] = c->d[k].jitter; ms.status[k] = c->d[k].status; ms.counters[k] = c->d[k].counters; }
     VG_HIP(vg_dstage_launch(&ms, st));
-    VG_MARK(12);
+    VG_MARK(16);
     vg_gemm_init(&g);
     vg_gemm_add(&g, c->beta, m2, 1, c->beta, 1, m2, c->X1, (int)m1, (int)m1, (int)m1, (int)m2);    // beta beta^T
     vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
     vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
     vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
-    if (warm && c->desc.warm_start && !(c->sub_mode && vg_sub_ident()))   // U = Q(t) Q(t-1)^T for the NEXT step's extrapolated start (both bases are final here)
+    if (predict)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.QtPrev, d.m, 1, d.QtPrev2, 1, d.m, d.U, d.m, d.m, d.m, d.m);
+            vg_gemm_add(&g, d.Ep, d.m, 1, d.Ep, 1, d.m, d.Wp, d.m, d.m, d.m, d.m);      // W = Qpred Qpred^T
         }
     VG_HIP(vg_gemm_launch(&g, st));
-    VG_MARK(13);
+    VG_MARK(17);
     VG_HIP(vg_final_launch(&ms, st));
-    VG_MARK(14);
+    VG_MARK(18);
 
     // 10. nothing to copy: the replay workgroups already left the new basis in QtPrev (next warm start, q(v), posterior)
     //     and the last workgroup of the final reduction wrote results + diagnostics into the pinned host block
@@ -666,8 +798,8 @@ static void graphs_clear(vggp_ctx* c) {
 }
 
 template <typename F>
-static int run_graph(vggp_ctx* c, int which, const VgGraphKey& key, hipStream_t st, F enqueue) {
-    if (!c->use_graph || c->prof) return enqueue();
+static int run_graph(vggp_ctx* c, int which, const VgGraphKey& key, hipStream_t st, F enqueue, bool bypass = false) {
+    if (!c->use_graph || c->prof || bypass) return enqueue();
     if (!c->gexec[which] || !(c->gkey[which] == key)) {
         if (c->gexec[which]) { (void)hipGraphExecDestroy(c->gexec[which]); c->gexec[which] = nullptr; }
         VG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -704,8 +836,6 @@ static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out
     out->extrap = vg_extrapolate(c);
     out->subspace = warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0;
     out->refine = warm && !out->subspace && vg_refine(c, out->extrap);
-    if (out->subspace && !c->sub_mode && vg_sub_ident())
-        for (int k = 0; k < 2; ++k) VG_HIP(vg_identity_launch(c->d[k].U, c->d[k].m, st));
     c->sub_mode = out->subspace;
     if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
         for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S})
@@ -727,15 +857,16 @@ static int set_theta(vggp_ctx* c, const double theta[5]) {
 // host side of the end of a step: the only synchronisation, then unpack the pinned block
 static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vggp_info* info, hipStream_t st) {
     VG_HIP(hipStreamSynchronize(st));
-    if (c->prof && c->ev_set[0] && c->ev_set[14]) {
-        // stage i spans event slot i -> i+1, except stage 6 (warm-start GEMMs) which starts at the finish marker
-        for (int i = 0; i < VGGP_NSTAGE; ++i) {
-            const int a = (i == 6) ? VGGP_NSTAGE + 1 : i, b = i + 1;
+    c->pred_consumed = false;              // the tail of this step left a fresh prediction in Ep / Fp / Wp
+    if (c->prof && c->nev > 1) {
+        for (int i = 1; i < c->nev; ++i) {
+            const int id = c->ev_stage[i];
             float ms = 0.f;
-            if (c->ev_set[a] && c->ev_set[b] && hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess) c->prof_ms[i] += ms;
+            if (id >= 0 && id < VGGP_NSTAGE && hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) == hipSuccess) c->prof_ms[id] += ms;
         }
         c->prof_steps++;
     }
+    c->nev = 0;
     if (c->h_out->seq != c->h_theta[5]) {       // the block was not written by THIS step (a launch was lost or reordered)
         vg_set_error("step %.0f: the result block carries sequence number %.0f (stale results)", c->h_theta[5], c->h_out->seq);
         c->warm_run = 0;
@@ -805,14 +936,18 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = set_theta(c, theta);
     if (rc) return rc;
-    if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
+    c->nev = 0;
     const VgGraphKey key{Y, payload, 0.0};
     VgStart sp;
     if ((rc = vg_start_prepare(c, c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev, st, &sp))) return rc;
     const bool extrap = sp.extrap;
+    // the Newton-Schulz step of the predicted basis accumulates into Fp: exactly once per prediction (a repeated partials
+    // call without a finish in between runs un-captured without it)
+    const bool apply_ns = extrap && !c->pred_consumed;
     rc = run_graph(c, extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, key, st,
-                   [&] { return vg_partials_enqueue(c, Y, payload, st, true, extrap); });
+                   [&] { return vg_partials_enqueue(c, Y, payload, st, true, extrap, false, apply_ns); }, extrap && !apply_ns);
     if (rc) return rc;
+    if (extrap) c->pred_consumed = true;
     c->have_partials = true;
     return VGGP_OK;
 }
@@ -845,18 +980,20 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = set_theta(c, theta);
     if (rc) return rc;
-    if (c->prof) for (int i = 0; i < VGGP_NSTAGE + 2; ++i) c->ev_set[i] = false;
+    c->nev = 0;
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
     const VgGraphKey key{Y, c->payload, yy_total};
     VgStart sp;
     if ((rc = vg_start_prepare(c, warm, st, &sp))) return rc;
     const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
+    const bool apply_ns = extrap && !c->pred_consumed;
     rc = run_graph(c, warm ? (subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
                             : VG_G_STEP_COLD, key, st, [&] {
-        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap);
+        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns);
         return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace);
-    });
+    }, extrap && !apply_ns);
     if (rc) return rc;
+    if (extrap) c->pred_consumed = true;
     c->have_partials = true;
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
@@ -1166,30 +1303,43 @@ extern "C" int vggp_gemm(vggp_ctx* c, const double* A, int64_t sa_m, int64_t sa_
     return VGGP_OK;
 }
 
-extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1inv, int64_t n1, const double* L2inv, int64_t n2,
-                               const double* Y, double* X, void* stream) {
+extern "C" int vggp_trsm(vggp_ctx* c, const double* L, int64_t m, const double* R, int64_t ncols, double* X, int trans,
+                         void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
-    VG_REQUIRE(L1inv && L2inv && Y && X && n1 >= 1 && n2 >= 1, "vggp_kron_solve: bad argument");
+    VG_REQUIRE(L && R && X && m >= 1 && m <= 16384 && ncols >= 1, "vggp_trsm: bad argument (1 <= m <= 16384)");
+    VG_REQUIRE(m * ncols < (1L << 31) && m * m < (1L << 31), "vggp_trsm: matrix too large");
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
-    int rc = vg_ensure_misc(c, 2 * (size_t)n1 * n2 * sizeof(double));
+    const long nb16 = (m + 15) / 16;
+    int rc = vg_ensure_misc(c, (size_t)nb16 * 256 * sizeof(double));
     if (rc) return rc;
-    double* T1 = (double*)c->misc;
-    double* T2 = T1 + n1 * n2;
-    VgGemmBatch g;
-    // X = L1^{-T} ( L1^{-1} Y L2^{-T} ) L2^{-1}
-    vg_gemm_init(&g);
-    vg_gemm_add(&g, L1inv, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1);        // L1inv Y
-    VG_HIP(vg_gemm_launch(&g, st));
-    vg_gemm_init(&g);
-    vg_gemm_add(&g, T1, n2, 1, L2inv, 1, n2, T2, (int)n2, (int)n1, (int)n2, (int)n2);       // . L2inv^T
-    VG_HIP(vg_gemm_launch(&g, st));
-    vg_gemm_init(&g);
-    vg_gemm_add(&g, L1inv, 1, n1, T2, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1);       // L1inv^T .
-    VG_HIP(vg_gemm_launch(&g, st));
-    vg_gemm_init(&g);
-    vg_gemm_add(&g, T1, n2, 1, L2inv, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2);        // . L2inv
-    VG_HIP(vg_gemm_launch(&g, st));
+    double* Dinv = (double*)c->misc;
+    VG_HIP(vg_tri_diaginv_launch(L, m, (int)m, Dinv, st));
+    if (X != R) VG_HIP(hipMemcpyAsync(X, R, sizeof(double) * m * ncols, hipMemcpyDeviceToDevice, st));
+    return trsm_inplace(L, m, m, Dinv, X, ncols, 1, ncols, trans ? 1 : 0, st);
+}
+
+extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const double* L2, int64_t n2, const double* Y,
+                               double* X, void* stream) {
+    if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
+    VG_REQUIRE(L1 && L2 && Y && X && n1 >= 1 && n2 >= 1 && n1 <= 16384 && n2 <= 16384, "vggp_kron_solve: bad argument");
+    VG_REQUIRE(n1 * n2 < (1L << 31) && n1 * n1 < (1L << 31) && n2 * n2 < (1L << 31), "vggp_kron_solve: matrix too large");
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const long nb1 = (n1 + 15) / 16, nb2 = (n2 + 15) / 16;
+    int rc = vg_ensure_misc(c, (size_t)(nb1 + nb2) * 256 * sizeof(double));
+    if (rc) return rc;
+    double* D1 = (double*)c->misc;
+    double* D2 = D1 + nb1 * 256;
+    VG_HIP(vg_tri_diaginv_launch(L1, n1, (int)n1, D1, st));
+    VG_HIP(vg_tri_diaginv_launch(L2, n2, (int)n2, D2, st));
+    if (X != Y) VG_HIP(hipMemcpyAsync(X, Y, sizeof(double) * n1 * n2, hipMemcpyDeviceToDevice, st));
+    // X = L1^{-T} ( L1^{-1} Y L2^{-T} ) L2^{-1}, all four solves in place on X ([n1][n2] row-major):
+    //   left solves see X as it is (row k = row of X); right solves see its transpose (row k = column k of X)
+    if ((rc = trsm_inplace(L1, n1, n1, D1, X, n2, 1, n2, 0, st))) return rc;        // L1 T = Y
+    if ((rc = trsm_inplace(L2, n2, n2, D2, X, 1, n2, n1, 0, st))) return rc;        // L2 T'^T = T^T      (T' = T L2^{-T})
+    if ((rc = trsm_inplace(L1, n1, n1, D1, X, n2, 1, n2, 1, st))) return rc;        // L1^T T'' = T'
+    if ((rc = trsm_inplace(L2, n2, n2, D2, X, 1, n2, n1, 1, st))) return rc;        // L2^T X^T = T''^T   (X = T'' L2^{-1})
     return VGGP_OK;
 }
 
@@ -1210,7 +1360,7 @@ extern "C" int vggp_profile(vggp_ctx* c, int enable) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_ENTER_DEVICE(c->device);
     if (enable && !c->ev[0])
-        for (int i = 0; i < VGGP_NSTAGE + 2; ++i) VG_HIP(hipEventCreate(&c->ev[i]));
+        for (int i = 0; i < VG_MAXEV; ++i) VG_HIP(hipEventCreate(&c->ev[i]));
     c->prof = enable != 0;
     return VGGP_OK;
 }

@@ -123,6 +123,23 @@ struct VgCholJob {
 hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st);
 hipError_t vg_chol_setup();   // opt-in to large dynamic LDS
 
+// ---- triangular solves by substitution (trsm.hip) -------------------------------------------------------------------
+struct VgTrsmJob {
+    const double* L;      // [m][ldl] lower-triangular Cholesky factor
+    const double* Dinv;   // inverses of its 16 x 16 diagonal blocks: block b at Dinv + b * dinv_blk, row stride dinv_ld
+                          // (the diagonal blocks of an explicit inverse [m][m]: dinv_blk = 16 * m + 16, dinv_ld = m)
+    const double* R;      // right-hand sides: element (row k, column c) at R[k * r_sk + c * r_sc]
+    double* X;            // solution, element (k, c) at X[k * x_sk + c * x_sc]  (may alias R)
+    long ldl, dinv_blk, dinv_ld;
+    long r_sk, r_sc, x_sk, x_sc;
+    long ncols;
+    int m;                // <= 256
+    int trans;            // 0: L X = R, 1: L^T X = R
+};
+hipError_t vg_trsm_launch(const VgTrsmJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_trsm_setup();
+hipError_t vg_tri_diaginv_launch(const double* L, long ldl, int m, double* out /* [ceil(m/16)][16][16] */, hipStream_t st);
+
 // ---- Jacobi eigensolver (eigh.hip) ---------------------------------------------
 #define VG_EIG_MAXSWEEP 60
 struct VgEigJob {

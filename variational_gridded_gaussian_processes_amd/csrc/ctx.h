@@ -2,12 +2,16 @@
 #pragma once
 #include "common.h"
 
+#define VG_MAXEV 40
+#define VG_NFORK 4
+
 struct VgDim {
     int kind = 0, basis = 0, n = 0, m = 0;
     double *x = nullptr, *grid = nullptr;
     double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
     double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
     double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr, *QtPrev2 = nullptr, *U = nullptr;
+    double *Ep = nullptr, *Fp = nullptr, *Wp = nullptr;      // prediction of the next start basis (finish_enqueue tail)
     double *TM = nullptr, *TH = nullptr, *E = nullptr, *F = nullptr, *RQ = nullptr, *RQsq = nullptr;
     double *chol_scratch = nullptr, *gwork = nullptr, *jitter = nullptr;
     double2* rotlog = nullptr;
@@ -63,9 +67,14 @@ struct vggp_ctx {
     // step runs on `own_stream`, a BLOCKING stream: it is implicitly ordered with the legacy default stream in both
     // directions (uploads / all-reduce issued by torch on stream 0 before, q(v) / posterior calls after).
     hipStream_t own_stream = nullptr;
+    // side stream for the branches of a step that do not depend on each other (extrapolated basis || factor + Cholesky;
+    // projection of Y || eigensolver chain); under capture the fork / join events become graph edges
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork[VG_NFORK] = {}, ev_join[VG_NFORK] = {};
     bool use_graph = true;
     hipGraphExec_t gexec[12] = {};
     VgGraphKey gkey[12];
+    bool pred_consumed = false;       // this prediction's Newton-Schulz step has been applied to Fp (it accumulates: once only)
     bool refine_next = false;
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start
     int sub_r_cap[2] = {0, 0};        // ranks the _S graphs were captured with
@@ -74,8 +83,9 @@ struct vggp_ctx {
     int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
     bool prof = false;
-    hipEvent_t ev[VGGP_NSTAGE + 2] = {};
-    bool ev_set[VGGP_NSTAGE + 2] = {};
+    hipEvent_t ev[VG_MAXEV] = {};
+    int ev_stage[VG_MAXEV] = {};      // stage charged with the time since the previous event (-1: clock restart)
+    int nev = 0;
     double prof_ms[VGGP_NSTAGE] = {};
     int prof_steps = 0;
 };
@@ -86,5 +96,6 @@ int vg_ensure_misc(vggp_ctx* c, size_t bytes);
 #define VG_DENSE_MB 128
 struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };
 int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st);
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false);
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false, bool fused = false,
+                        bool apply_ns = false);
 void vg_masked_free(vggp_ctx* c);

@@ -238,10 +238,18 @@ class Engine:
                                  B.stride(1), Cm.data_ptr(), N, M, N, K, _stream(self.device)))
         return Cm
 
-    def kron_solve(self, L1inv: torch.Tensor, L2inv: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    def kron_solve(self, L1: torch.Tensor, L2: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """X = K1^{-1} Y K2^{-T} with K_d = L_d L_d^T from the Cholesky factors (four triangular solves by substitution)."""
         n1, n2 = Y.shape
         X = torch.empty_like(Y)
-        check(self.lib.vggp_kron_solve(self._h, _ptr(L1inv), n1, _ptr(L2inv), n2, _ptr(Y), _ptr(X), _stream(self.device)))
+        check(self.lib.vggp_kron_solve(self._h, _ptr(L1), n1, _ptr(L2), n2, _ptr(Y), _ptr(X), _stream(self.device)))
+        return X
+
+    def trsm(self, L: torch.Tensor, R: torch.Tensor, trans: bool = False) -> torch.Tensor:
+        """Solve L X = R (or L^T X = R) for lower-triangular L [m, m] and R [m, ncols] by substitution."""
+        m, ncols = R.shape
+        X = torch.empty_like(R)
+        check(self.lib.vggp_trsm(self._h, _ptr(L), m, _ptr(R), ncols, _ptr(X), 1 if trans else 0, _stream(self.device)))
         return X
 
     def profile(self, enable: bool = True) -> None:
