@@ -21,8 +21,11 @@
  *   Y        : observations on the local grid shard, [n2][n1] row-major,
  *              Y[j][i] = y(x1[i], x2[j])  (x1 fastest: utils/datagenerators.py:70-72)
  *   inducing index u = i1*m2 + i2 (kronecker_structure.py:805, :822)
- *   multi-GPU: the grid is sharded along the slow storage axis (rows j of Y, i.e.
- *              dimension 2); dimension 1 and all m-space algebra are replicated.
+ *   multi-GPU: one process (one context) per GPU; the grid is sharded along the slow storage axis (rows j of Y,
+ *              i.e. dimension 2); dimension 1 and all m-space algebra are replicated.  The context OWNS the collective
+ *              (an RCCL communicator created in vggp_create, or a host callback): vggp_elbo_step on an n_ranks > 1
+ *              context is  partials -> ONE sum all-reduce of the packed payload -> finish  on one stream with one host
+ *              synchronisation, and every rank returns the identical value and gradient.
  */
 #ifndef VGGP_H
 #define VGGP_H
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VGGP_VERSION 100          /* 0.1.0 */
+#define VGGP_VERSION 200          /* 0.2.0 */
 
 /* error codes */
 #define VGGP_OK        0
@@ -43,6 +46,7 @@ extern "C" {
 #define VGGP_ENOMEM   -4
 #define VGGP_ESTATE   -5          /* call order (e.g. finish before partials)      */
 #define VGGP_ENOCONV  -6          /* Jacobi eigensolver hit its sweep limit        */
+#define VGGP_ERCCL    -7          /* the collective failed (RCCL error, RCCL not loadable, callback error) */
 
 /* kernel family of one dimension (gpytorch MaternKernel(nu) / the build's RBF) */
 #define VGGP_KIND_MATERN12 0
@@ -105,8 +109,25 @@ int         vggp_version(void);
 const char* vggp_last_error(void);
 
 /* lifecycle ---------------------------------------------------------------- */
-int vggp_create(vggp_ctx** out, int device);
+/* One context per (process, GPU).  n_ranks = 1: single GPU (rank, unique_id ignored).  n_ranks > 1: this process is rank
+ * `rank` of a row-sharded job; `unique_id` (VGGP_UNIQUE_ID_BYTES bytes, generated on rank 0 by vggp_unique_id and
+ * distributed to the other ranks by the host program) creates the context's RCCL communicator (collective call: every
+ * rank must be inside vggp_create).  unique_id = NULL with n_ranks > 1 creates no communicator: the caller installs a host
+ * transport with vggp_set_allreduce before the first step.  (A unique id with n_ranks = 1 creates a communicator of size
+ * one and the step runs the multi-rank sequence through it: the RCCL path on a one-GPU box.) */
+#define VGGP_UNIQUE_ID_BYTES 128
+int vggp_create(vggp_ctx** out, int device, int n_ranks, int rank, const void* unique_id);
 int vggp_destroy(vggp_ctx* ctx);
+int vggp_unique_id(void* out /* VGGP_UNIQUE_ID_BYTES */);
+/* Host-callback transport: fn sums `count` doubles at the HOST address `buf` over all ranks, in place, and returns 0.
+ * The library stages the payload through pinned memory around the call.  Used by the multi-rank rehearsal on one GPU
+ * (gloo; RCCL refuses several ranks on one device) and as the seam for other transports. */
+typedef int (*vggp_allreduce_fn)(void* user, double* buf, int64_t count);
+int vggp_set_allreduce(vggp_ctx* ctx, vggp_allreduce_fn fn, void* user);
+/* The context's sum all-reduce on a DEVICE buffer (in place; returns after the result is complete). */
+int vggp_allreduce(vggp_ctx* ctx, double* buf, int64_t count, void* stream);
+/* n_ranks, rank and the transport in use (0 none, 1 RCCL, 2 host callback); any output may be NULL. */
+int vggp_comm_info(const vggp_ctx* ctx, int* n_ranks, int* rank, int* transport);
 /* (Re)plan the context for a problem: allocates the workspace arena (no allocation
  * happens per step afterwards) and uploads coordinates / meshes.
  * Replaces: KroneckerStructure.__init__ + Matern12GriddedGP.__init__ bookkeeping
@@ -120,16 +141,16 @@ int64_t vggp_workspace_bytes(const vggp_ctx* ctx);
 /* One ELBO step = value + gradient w.r.t. theta.  Replaces KroneckerStructure._elbo
  * (kronecker_structure.py:249-278) AND the autograd backward of the notebook loop
  * (5_gridded_kronecker_structure_models.ipynb cell 26).
- *   Y        DEVICE [n2][n1]
- *   yy_total sum of y^2 over ALL ranks (constant of the data; vggp_sumsq helps)
+ *   Y        DEVICE [n2][n1]  (this rank's row slab)
+ *   yy_total sum of y^2 over ALL ranks (constant of the data; vggp_sumsq returns it)
  *   elbo_out, grad_out[5]  HOST outputs (the only host sync of the step)
  * Single-rank convenience = vggp_elbo_partials + vggp_elbo_finish. */
 int vggp_elbo_step(vggp_ctx* ctx, const double* Y, double yy_total, const double theta[5],
                    double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 
-/* Multi-GPU split: partials fills `payload` (DEVICE, vggp_payload_len doubles) with this
- * rank's contribution; the caller sums it over ranks with ONE all-reduce (RCCL via
- * torch.distributed) and passes the reduced buffer to finish. */
+/* The two halves of the step, for callers that carry the all-reduce themselves (vggp_elbo_step on a multi-rank context
+ * does all three): partials fills `payload` (DEVICE, vggp_payload_len doubles) with this rank's contribution; the caller
+ * sums it over ranks with ONE all-reduce and passes the reduced buffer to finish. */
 int vggp_elbo_partials(vggp_ctx* ctx, const double* Y, const double theta[5],
                        double* payload, void* stream);
 int vggp_elbo_finish(vggp_ctx* ctx, const double* payload, double yy_total, const double theta[5],
@@ -205,10 +226,15 @@ int vggp_gemm(vggp_ctx* ctx, const double* A, int64_t sa_m, int64_t sa_k,
  * updates (csrc/trsm.hip).  Replaces the triangular solves inside lazify(Kuu).inv_matmul (kronecker_structure.py:269). */
 int vggp_trsm(vggp_ctx* ctx, const double* L, int64_t m, const double* R, int64_t ncols, double* X, int trans, void* stream);
 
-/* Kronecker solve  X = K1^{-1} Y K2^{-T},  K_d = L_d L_d^T,  from the CHOLESKY FACTORS (BASELINE metric ii): four
- * triangular solves by substitution, X = L1^{-T} (L1^{-1} Y L2^{-T}) L2^{-1}, never materialising K1 (x) K2 nor an inverse
- * of a factor.  L1 [n1][n1], L2 [n2][n2] lower-triangular (e.g. from vggp_cholesky_inverse), Y, X DEVICE [n1][n2]
- * (X may alias Y).  Replaces Kuu.inv_matmul(.) with Kuu = torch.kron(Kuu_1, Kuu_2) (kronecker_structure.py:269, :805). */
+/* Kronecker solve  X = K1^{-1} Y K2^{-T},  K_d = L_d L_d^T,  from the CHOLESKY FACTORS (BASELINE metric ii; nothing is
+ * pre-inverted by the caller, the whole solve is inside this call), X = L1^{-T} (L1^{-1} Y L2^{-T}) L2^{-1}, never
+ * materialising K1 (x) K2.  n1, n2 <= 128: four triangular solves by substitution (vggp_trsm's strip kernel).  Larger
+ * factors: their 128 x 128 diagonal blocks are inverted by substitution on the identity, the rest of L^{-1} follows by
+ * block doubling (two MFMA GEMM launches per level), and the four applications are triangular-aware MFMA GEMMs that skip
+ * the zero half -- a substitution sweep over n / 128 block rows is a chain of 2 n / 128 dependent launches per solve
+ * (1.3 ms at n = 1024 against 0.3 ms; VGGP_KRON_SUBST=1 selects it).  L1 [n1][n1], L2 [n2][n2] lower-triangular
+ * (e.g. from vggp_cholesky_inverse), Y, X DEVICE [n1][n2] (X may alias Y).
+ * Replaces Kuu.inv_matmul(.) with Kuu = torch.kron(Kuu_1, Kuu_2) (kronecker_structure.py:269, :805). */
 int vggp_kron_solve(vggp_ctx* ctx, const double* L1, int64_t n1, const double* L2, int64_t n2,
                     const double* Y, double* X, void* stream);
 
@@ -220,7 +246,7 @@ int         vggp_profile(vggp_ctx* ctx, int enable);
 int         vggp_profile_read(vggp_ctx* ctx, double ms_out[VGGP_NSTAGE], int32_t* steps_out, int reset);
 const char* vggp_stage_name(int stage);
 
-/* sum of squares of a DEVICE array (for yy_total); result to HOST. */
+/* sum of squares of a DEVICE array, summed over all ranks of the context (yy_total); result to HOST. */
 int vggp_sumsq(vggp_ctx* ctx, const double* y, int64_t n, double* out, void* stream);
 
 #ifdef __cplusplus

@@ -36,16 +36,16 @@ def test_struct_layouts_match_header():
 
 
 def test_version_and_stage_names(lib):
-    assert lib.vggp_version() == 100
-    names = [lib.vggp_stage_name(i).decode() for i in range(14)]
-    assert len(set(names)) == 14 and any(n.startswith("jacobi_eigh") for n in names)
+    assert lib.vggp_version() == 200
+    names = [lib.vggp_stage_name(i).decode() for i in range(20)]
+    assert len(set(names)) == 20 and any(n.startswith("jacobi_eigh") for n in names)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_fails_loudly_without_gpu(lib):
     from variational_gridded_gaussian_processes_amd import Engine
     h = C.c_void_p()
-    assert lib.vggp_create(C.byref(h), 0) == -3          # VGGP_EHIP, never a silent CPU path
+    assert lib.vggp_create(C.byref(h), 0, 1, 0, None) == -3          # VGGP_EHIP, never a silent CPU path
     assert b"hipGetDeviceCount" in lib.vggp_last_error()
     with pytest.raises(RuntimeError):
         Engine()

@@ -1,5 +1,7 @@
-"""2 ranks on ONE GPU (gloo carries the collective; on the 8-GPU node bench.py uses RCCL): the product seam
-vggp_elbo_partials -> all_reduce -> vggp_elbo_finish through ShardedStep equals the single-rank step and the oracle."""
+"""Several ranks on ONE GPU: the in-library multi-rank step (vggp_elbo_step on an n_ranks > 1 context = partials ->
+the context's all-reduce -> finish, csrc/comm.hip) with the host-callback transport carrying the payload over gloo
+(RCCL refuses several ranks on one device; the RCCL transport itself is exercised with a communicator of size one in
+test_rccl_transport_size_one).  Every rank equals the single-rank step and the oracle."""
 import os
 import sys
 
@@ -22,13 +24,14 @@ def _worker(rank, world, port, q, kind="matern32", m1=M1, m2=M2):
     import torch.distributed as dist
     from oracle import dense as D
     from variational_gridded_gaussian_processes_amd import Engine
-    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, shard_rows
+    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, make_engine, shard_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         X, y, x1, x2 = D.gen_grid(N1, N2)
         rows = shard_rows(N2, rank, world)
-        eng = Engine(0)
+        eng = make_engine(0, transport="gloo")
+        assert eng.n_ranks == world and eng.transport == "callback"
         eng.plan(kind, "points", np.linspace(0, 1, m1), x1, kind, "points", np.linspace(0, 1, m2), x2[rows],
                  n_total=N1 * N2, warm_start=True)
         Y = torch.tensor(y.reshape(N2, N1)[rows], device="cuda:0")
@@ -119,7 +122,7 @@ def _config4_worker(rank, world, port, q):
     import torch.distributed as dist
     from oracle import dense as D
     from variational_gridded_gaussian_processes_amd import Engine
-    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, shard_rows
+    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, make_engine, shard_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -128,7 +131,7 @@ def _config4_worker(rank, world, port, q):
         rows = shard_rows(C4_N, rank, world)
         assert rows.stop - rows.start == C4_N // world           # the 1024-row x 4096 slab of the config
         g = np.linspace(0, 1, C4_M)
-        eng = Engine(0)
+        eng = make_engine(0, transport="gloo")
         eng.plan("rbf", "points", g, x1, "rbf", "points", g, x2[rows], n_total=C4_N * C4_N, warm_start=True)
         Y = torch.tensor(y.reshape(C4_N, C4_N)[rows], device="cuda:0")
         sh = ShardedStep(eng)
@@ -177,3 +180,33 @@ def test_config4_four_ranks_1024x4096_slabs_vs_structured_oracle(engine):
         assert np.abs(mean - rm).max() <= 1e-6 * np.abs(rm).max()
         # the posterior variance is 1e-6 of the prior variance here (16.8 M observations): checked against the prior scale
         assert np.abs(var - rv).max() <= 1e-8 * max(C4_THETA[2] * C4_THETA[3], np.abs(rv).max())
+
+
+def test_rccl_transport_size_one(engine):
+    """The RCCL transport on the one GPU of the test box: a communicator of size one (unique id from vggp_unique_id,
+    ncclCommInitRank inside vggp_create).  The step then runs the multi-rank sequence -- partials graph, ncclAllReduce of the
+    packed payload ON THE STEP'S STREAM, finish graph, one host synchronisation -- and must equal the fused single-rank step
+    bit for bit along a warm-started trajectory; vggp_allreduce / vggp_sumsq go through the same communicator."""
+    from oracle import dense as D, kron as Kr
+    from variational_gridded_gaussian_processes_amd import Engine
+    n1, n2, m = 96, 70, 24
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    g = np.linspace(0, 1, m)
+    eng = Engine(0, 1, 0, Engine.unique_id())
+    assert eng.transport == "rccl"
+    Y = torch.tensor(y.reshape(n2, n1), device="cuda")
+    t = torch.arange(5, dtype=torch.float64, device="cuda")
+    assert torch.equal(eng.allreduce(t.clone()), t)
+    f1, f2 = Kr.Factor("points", "rbf", g, x1), Kr.Factor("points", "rbf", g, x2)
+    for e in (eng, engine):
+        e.plan("rbf", "points", g, x1, "rbf", "points", g, x2, warm_start=True)
+    yy = eng.sumsq(Y)
+    assert yy == engine.sumsq(Y)
+    for k in range(6):
+        th = np.array(THETA) * (1.0 + 0.01 * k)
+        e_r, g_r, i_r = eng.elbo_step(Y, yy, th)
+        e_s, g_s, i_s = engine.elbo_step(Y, yy, th)
+        ref = Kr.elbo_step(y.reshape(n2, n1), f1, f2, th)
+        assert abs(e_r - ref.elbo) <= 1e-8 * abs(ref.elbo) and np.abs(g_r - ref.grad).max() <= 1e-6 * np.abs(ref.grad).max()
+        assert abs(e_r - e_s) <= 1e-12 * abs(e_s)
+    eng.close()

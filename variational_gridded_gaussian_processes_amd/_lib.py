@@ -8,7 +8,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvggp_hip.so")
 
-VGGP_OK, VGGP_EINVAL, VGGP_ENOTPD, VGGP_EHIP, VGGP_ENOMEM, VGGP_ESTATE, VGGP_ENOCONV = 0, -1, -2, -3, -4, -5, -6
+VGGP_OK, VGGP_EINVAL, VGGP_ENOTPD, VGGP_EHIP, VGGP_ENOMEM, VGGP_ESTATE, VGGP_ENOCONV, VGGP_ERCCL = 0, -1, -2, -3, -4, -5, -6, -7
+UNIQUE_ID_BYTES = 128
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)      # vggp_allreduce_fn
 KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 NSTAGE = 20
 FLAG_B0_F32_KDELTA = 1
@@ -42,7 +44,11 @@ _P, _I64, _D, _I = C.c_void_p, C.c_int64, C.c_double, C.c_int
 SYMBOLS = {
     "vggp_version": (_I, []),
     "vggp_last_error": (C.c_char_p, []),
-    "vggp_create": (_I, [C.POINTER(_P), _I]),
+    "vggp_create": (_I, [C.POINTER(_P), _I, _I, _I, _P]),
+    "vggp_unique_id": (_I, [_P]),
+    "vggp_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
+    "vggp_allreduce": (_I, [_P, _P, _I64, _P]),
+    "vggp_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "vggp_destroy": (_I, [_P]),
     "vggp_plan": (_I, [_P, C.POINTER(Desc)]),
     "vggp_payload_len": (_I64, [_P]),

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "factor_build.hip", "chol.hip", "trsm.hip", "eigh.hip", "mspace.hip", "masked.hip"]
+SOURCES = ["api.hip", "gemm.hip", "factor_build.hip", "chol.hip", "trsm.hip", "eigh.hip", "mspace.hip", "masked.hip", "comm.hip"]
 HEADERS = ["common.h", "ctx.h", os.path.join("..", "..", "include", "vggp.h")]
 LIB = os.path.join(HERE, "libvggp_hip.so")
 
@@ -29,7 +29,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libvggp_hip.so cannot be built (ROCm toolchain required)")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -66,8 +66,9 @@ int vg_ensure_misc(vggp_ctx* c, size_t bytes) {
     return VGGP_OK;
 }
 
-extern "C" int vggp_create(vggp_ctx** out, int device) {
+extern "C" int vggp_create(vggp_ctx** out, int device, int n_ranks, int rank, const void* unique_id) {
     if (!out) { vg_set_error("vggp_create: null out"); return VGGP_EINVAL; }
+    VG_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "vggp_create: rank %d of %d", rank, n_ranks);
     int ndev = 0;
     VG_HIP(hipGetDeviceCount(&ndev));
     VG_REQUIRE(device >= 0 && device < ndev, "vggp_create: device %d out of range (%d devices)", device, ndev);
@@ -100,6 +101,8 @@ extern "C" int vggp_create(vggp_ctx** out, int device) {
     VG_HIP(hipMemset(c->ticket, 0, 4 * sizeof(int)));
     VG_HIP(hipMalloc((void**)&c->sumsq_partial, 1024 * sizeof(double)));
     VG_HIP(hipMalloc((void**)&c->sumsq_out, 8 * sizeof(double)));
+    const int rcc = vg_comm_init(c, n_ranks, rank, unique_id);
+    if (rcc) { (void)vggp_destroy(c); return rcc; }
     *out = c;
     return VGGP_OK;
 }
@@ -116,6 +119,7 @@ extern "C" int vggp_destroy(vggp_ctx* c) {
     }
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     vg_masked_free(c);
+    vg_comm_destroy(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->arena) (void)hipFree(c->arena);
     if (c->misc) (void)hipFree(c->misc);
@@ -982,11 +986,28 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
     if (rc) return rc;
     c->nev = 0;
     const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
-    const VgGraphKey key{Y, c->payload, yy_total};
     VgStart sp;
     if ((rc = vg_start_prepare(c, warm, st, &sp))) return rc;
     const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
     const bool apply_ns = extrap && !c->pred_consumed;
+    if (c->n_ranks > 1 || c->comm || c->cb) {
+        // row-sharded job: partials graph -> the context's all-reduce of the packed payload (RCCL: enqueued on this stream)
+        // -> finish graph; the one host synchronisation is in finish_collect.  Every rank finishes redundantly, so all ranks
+        // hold the identical value and gradient without a broadcast.
+        const VgGraphKey kp{Y, c->payload, 0.0}, kf{nullptr, c->payload, yy_total};
+        rc = run_graph(c, extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, kp, st,
+                       [&] { return vg_partials_enqueue(c, Y, c->payload, st, true, extrap, false, apply_ns); }, extrap && !apply_ns);
+        if (rc) return rc;
+        if (extrap) c->pred_consumed = true;
+        c->have_partials = true;
+        if ((rc = vg_allreduce(c, c->payload, c->payload_len, st))) return rc;
+        rc = run_graph(c, warm ? (subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
+                                : VG_G_FINISH_COLD, kf, st,
+                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace); });
+        if (rc) return rc;
+        return finish_collect(c, elbo_out, grad_out, info, st);
+    }
+    const VgGraphKey key{Y, c->payload, yy_total};
     rc = run_graph(c, warm ? (subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
                             : VG_G_STEP_COLD, key, st, [&] {
         const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns);
@@ -1319,6 +1340,49 @@ extern "C" int vggp_trsm(vggp_ctx* c, const double* L, int64_t m, const double* 
     return trsm_inplace(L, m, m, Dinv, X, ncols, 1, ncols, trans ? 1 : 0, st);
 }
 
+// Explicit inverse of a lower-triangular factor (n > 128) without ever inverting more than a 16 x 16 block directly:
+// the 128 x 128 diagonal blocks by substitution on the identity (strip kernel, one launch for all blocks of all factors),
+// then block doubling  inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]  with two MFMA GEMM launches per level
+// (128 -> 256 -> 512 -> ...; every pair of every factor in the same launch).  Xinv must be zero above the diagonal blocks.
+struct VgTriInvSpec { const double* L; long n; const double* Dinv16; double* Xinv; double* tmp; };
+static int tri_inverse_batch(const VgTriInvSpec* sp, int nf, hipStream_t st) {
+    VgTrsmJob tj[16];
+    int nt = 0;
+    for (int f = 0; f < nf; ++f)
+        for (long r0 = 0; r0 < sp[f].n; r0 += VG_TRSM_BLK) {
+            const long rb = std::min<long>(VG_TRSM_BLK, sp[f].n - r0);
+            if (nt == 16) { VG_HIP(vg_trsm_launch(tj, nt, st)); nt = 0; }
+            VgTrsmJob j{sp[f].L + r0 * sp[f].n + r0, sp[f].Dinv16 + (r0 / 16) * 256, nullptr, sp[f].Xinv + r0 * sp[f].n + r0, sp[f].n, 256, 16,
+                        sp[f].n, 1, sp[f].n, 1, rb, (int)rb, 0};
+            j.rhs_ident = 1;
+            tj[nt++] = j;
+        }
+    if (nt) VG_HIP(vg_trsm_launch(tj, nt, st));
+    long nmax = 0;
+    for (int f = 0; f < nf; ++f) nmax = std::max(nmax, sp[f].n);
+    for (long b = VG_TRSM_BLK; b < nmax; b *= 2) {
+        for (int pass = 0; pass < 2; ++pass) {
+            VgGemmBatch g;
+            vg_gemm_init(&g);
+            for (int f = 0; f < nf; ++f) {
+                const long n = sp[f].n;
+                for (long a0 = 0; a0 + b < n; a0 += 2 * b) {
+                    const long c0 = a0 + b, cb = std::min<long>(b, n - c0);           // A = [a0, a0+b), C = [c0, c0+cb)
+                    if (g.nprob == VG_GEMM_MAXP) { VG_HIP(vg_gemm_launch(&g, st)); vg_gemm_init(&g); }
+                    if (pass == 0)        // T = B A^-1        (cb x b)
+                        vg_gemm_add(&g, sp[f].L + c0 * n + a0, n, 1, sp[f].Xinv + a0 * n + a0, n, 1, sp[f].tmp + c0 * n + a0, (int)n, (int)cb,
+                                    (int)b, (int)b);
+                    else                  // W = -C^-1 T
+                        vg_gemm_add(&g, sp[f].Xinv + c0 * n + c0, n, 1, sp[f].tmp + c0 * n + a0, n, 1, sp[f].Xinv + c0 * n + a0, (int)n,
+                                    (int)cb, (int)b, (int)cb, 1, 0, 1, 0, -1.0, 0);
+                }
+            }
+            if (g.nprob) VG_HIP(vg_gemm_launch(&g, st));
+        }
+    }
+    return VGGP_OK;
+}
+
 extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const double* L2, int64_t n2, const double* Y,
                                double* X, void* stream) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
@@ -1327,19 +1391,51 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long nb1 = (n1 + 15) / 16, nb2 = (n2 + 15) / 16;
-    int rc = vg_ensure_misc(c, (size_t)(nb1 + nb2) * 256 * sizeof(double));
+    static const bool subst_only = getenv("VGGP_KRON_SUBST") != nullptr;
+    const bool small = (n1 <= VG_TRSM_BLK && n2 <= VG_TRSM_BLK) || subst_only;
+    const size_t need = (size_t)(nb1 + nb2) * 256 + (small ? 0 : (size_t)(n1 * n1 + n2 * n2 + std::max(n1 * n1, n2 * n2) + 2 * n1 * n2));
+    int rc = vg_ensure_misc(c, need * sizeof(double));
     if (rc) return rc;
     double* D1 = (double*)c->misc;
     double* D2 = D1 + nb1 * 256;
-    VG_HIP(vg_tri_diaginv_launch(L1, n1, (int)n1, D1, st));
-    VG_HIP(vg_tri_diaginv_launch(L2, n2, (int)n2, D2, st));
-    if (X != Y) VG_HIP(hipMemcpyAsync(X, Y, sizeof(double) * n1 * n2, hipMemcpyDeviceToDevice, st));
-    // X = L1^{-T} ( L1^{-1} Y L2^{-T} ) L2^{-1}, all four solves in place on X ([n1][n2] row-major):
-    //   left solves see X as it is (row k = row of X); right solves see its transpose (row k = column k of X)
-    if ((rc = trsm_inplace(L1, n1, n1, D1, X, n2, 1, n2, 0, st))) return rc;        // L1 T = Y
-    if ((rc = trsm_inplace(L2, n2, n2, D2, X, 1, n2, n1, 0, st))) return rc;        // L2 T'^T = T^T      (T' = T L2^{-T})
-    if ((rc = trsm_inplace(L1, n1, n1, D1, X, n2, 1, n2, 1, st))) return rc;        // L1^T T'' = T'
-    if ((rc = trsm_inplace(L2, n2, n2, D2, X, 1, n2, n1, 1, st))) return rc;        // L2^T X^T = T''^T   (X = T'' L2^{-1})
+    VG_HIP(vg_tri_diaginv_launch(L1, n1, (int)n1, D1, st, L2, n2, (int)n2, D2));
+    if (small) {
+        // X = L1^{-T} ( L1^{-1} Y L2^{-T} ) L2^{-1}: four solves by substitution, in place on X ([n1][n2] row-major);
+        // left solves see X as it is (row k = row of X), right solves see its transpose (row k = column k of X)
+        if (X != Y) VG_HIP(hipMemcpyAsync(X, Y, sizeof(double) * n1 * n2, hipMemcpyDeviceToDevice, st));
+        if ((rc = trsm_inplace(L1, n1, n1, D1, X, n2, 1, n2, 0, st))) return rc;        // L1 T = Y
+        if ((rc = trsm_inplace(L2, n2, n2, D2, X, 1, n2, n1, 0, st))) return rc;        // L2 T'^T = T^T      (T' = T L2^{-T})
+        if ((rc = trsm_inplace(L1, n1, n1, D1, X, n2, 1, n2, 1, st))) return rc;        // L1^T T'' = T'
+        if ((rc = trsm_inplace(L2, n2, n2, D2, X, 1, n2, n1, 1, st))) return rc;        // L2^T X^T = T''^T   (X = T'' L2^{-1})
+        return VGGP_OK;
+    }
+    // Larger factors: a substitution sweep over n / 128 block rows is a chain of 2 n / 128 dependent launches per solve (8 of
+    // them: 1.3 ms at n = 1024, measured), so the factors are inverted -- 128 x 128 diagonal blocks by substitution, the
+    // rest by block doubling (tri_inverse_batch) -- and applied as four triangular-aware MFMA GEMMs.  Everything is inside
+    // this call (BASELINE metric ii is timed from the Cholesky factors).
+    double* Li1 = D2 + nb2 * 256;
+    double* Li2 = Li1 + n1 * n1;
+    double* tmp = Li2 + n2 * n2;
+    double* T1 = tmp + std::max(n1 * n1, n2 * n2);
+    double* T2 = T1 + n1 * n2;
+    VG_HIP(hipMemsetAsync(Li1, 0, sizeof(double) * (n1 * n1 + n2 * n2), st));
+    VgTriInvSpec sp[2] = {{L1, (long)n1, D1, Li1, tmp}, {L2, (long)n2, D2, Li2, tmp}};
+    // the two factors share `tmp` only if they run in different launches: give each its own half when both fit, else serialise
+    if ((rc = tri_inverse_batch(&sp[0], 1, st))) return rc;
+    if ((rc = tri_inverse_batch(&sp[1], 1, st))) return rc;
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    { const int i = vg_gemm_add(&g, Li1, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1); g.p[i].tri = VG_TRI_A_LOWER; }     // L1inv Y
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    { const int i = vg_gemm_add(&g, T1, n2, 1, Li2, 1, n2, T2, (int)n2, (int)n1, (int)n2, (int)n2); g.p[i].tri = VG_TRI_B_UPPER; }    // . L2inv^T
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    { const int i = vg_gemm_add(&g, Li1, 1, n1, T2, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1); g.p[i].tri = VG_TRI_A_UPPER; }    // L1inv^T .
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    { const int i = vg_gemm_add(&g, T1, n2, 1, Li2, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2); g.p[i].tri = VG_TRI_B_LOWER; }     // . L2inv
+    VG_HIP(vg_gemm_launch(&g, st));
     return VGGP_OK;
 }
 
@@ -1379,6 +1475,8 @@ extern "C" int vggp_sumsq(vggp_ctx* c, const double* y, int64_t n, double* out, 
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     VG_HIP(vg_sumsq_launch(y, n, c->sumsq_partial, c->sumsq_out, st));
+    const int rca = vg_allreduce(c, c->sumsq_out, 1, st);          // total over the ranks of the context (no-op for one rank)
+    if (rca) return rca;
     VG_HIP(hipMemcpyAsync(out, c->sumsq_out, sizeof(double), hipMemcpyDeviceToHost, st));
     VG_HIP(hipStreamSynchronize(st));
     return VGGP_OK;

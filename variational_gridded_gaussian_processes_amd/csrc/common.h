@@ -64,7 +64,13 @@ struct VgGemmP {
     int kchunk;        // K elements per split (multiple of VG_BK)
     double alpha;      // C = (accum ? C : 0) + alpha * A B
     int accum;
+    int tri;           // VG_TRI_*: one operand is triangular, tiles skip the k-range where it is zero (at 128-granularity)
 };
+#define VG_TRI_NONE 0
+#define VG_TRI_A_LOWER 1   // op(A)[i][k] = 0 for k > i:  k < roundup128(row0 + T)
+#define VG_TRI_A_UPPER 2   // op(A)[i][k] = 0 for k < i:  k >= rounddown128(row0)
+#define VG_TRI_B_UPPER 3   // op(B)[k][j] = 0 for k > j:  k < roundup128(col0 + T)
+#define VG_TRI_B_LOWER 4   // op(B)[k][j] = 0 for k < j:  k >= rounddown128(col0)
 struct VgGemmBatch {
     int nprob;
     int total_tiles;
@@ -133,12 +139,14 @@ struct VgTrsmJob {
     long ldl, dinv_blk, dinv_ld;
     long r_sk, r_sc, x_sk, x_sc;
     long ncols;
-    int m;                // <= 256
+    int m;                // <= 128 (larger factors are blocked by the caller, api.hip trsm_batch)
     int trans;            // 0: L X = R, 1: L^T X = R
+    int rhs_ident = 0;    // 1: R is the m x m identity (generated in registers, R is not read): X = L^{-1} resp. L^{-T}
 };
 hipError_t vg_trsm_launch(const VgTrsmJob* jobs, int njobs, hipStream_t st);
 hipError_t vg_trsm_setup();
-hipError_t vg_tri_diaginv_launch(const double* L, long ldl, int m, double* out /* [ceil(m/16)][16][16] */, hipStream_t st);
+hipError_t vg_tri_diaginv_launch(const double* L, long ldl, int m, double* out /* [ceil(m/16)][16][16] */, hipStream_t st,
+                                 const double* L2 = nullptr, long ldl2 = 0, int m2 = 0, double* out2 = nullptr);   // optional second matrix
 
 // ---- Jacobi eigensolver (eigh.hip) ---------------------------------------------
 #define VG_EIG_MAXSWEEP 60

@@ -79,6 +79,13 @@ struct vggp_ctx {
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start
     int sub_r_cap[2] = {0, 0};        // ranks the _S graphs were captured with
     bool sub_mode = false;            // the current step uses the subspace start (U then holds the identity)         // the last step ended in the polish in both dimensions: refine the next start basis
+    // the context's collective (comm.hip)
+    int n_ranks = 1, rank = 0;
+    void* comm = nullptr;             // ncclComm_t
+    vggp_allreduce_fn cb = nullptr;   // host-callback transport (rehearsal / other transports)
+    void* cb_user = nullptr;
+    double* h_stage = nullptr;        // pinned staging of the callback transport
+    long h_stage_count = 0;
     long seq = 0;                     // step sequence number (h_theta[5] -> device theta[5] -> VgHostOut::seq)
     int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
@@ -92,6 +99,9 @@ struct vggp_ctx {
 
 
 int vg_ensure_misc(vggp_ctx* c, size_t bytes);
+int vg_comm_init(vggp_ctx* c, int n_ranks, int rank, const void* unique_id);
+void vg_comm_destroy(vggp_ctx* c);
+int vg_allreduce(vggp_ctx* c, double* buf, long count, hipStream_t st);
 // blocked dense Cholesky + inverse for matrices beyond one workgroup (masked.hip); S is destroyed; status != 0 on failure
 #define VG_DENSE_MB 128
 struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };

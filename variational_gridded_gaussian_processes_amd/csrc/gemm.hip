@@ -56,8 +56,14 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
     t -= ks * tiles;
     const int tm = t / p.tiles_n, tn = t - (t / p.tiles_n) * p.tiles_n;
     const int row0 = tm * T, col0 = tn * T;
-    const int k_begin = ks * p.kchunk;
-    const int k_end = min(p.K, k_begin + p.kchunk);
+    int k_begin = ks * p.kchunk;
+    int k_end = min(p.K, k_begin + p.kchunk);
+    if (p.tri) {          // triangular operand: skip the k-range where it vanishes (whole 128-blocks; split-K is not combined with it)
+        if (p.tri == VG_TRI_A_LOWER) k_end = min(k_end, ((row0 + T + 127) >> 7) << 7);
+        else if (p.tri == VG_TRI_A_UPPER) k_begin = max(k_begin, (row0 >> 7) << 7);
+        else if (p.tri == VG_TRI_B_UPPER) k_end = min(k_end, ((col0 + T + 127) >> 7) << 7);
+        else k_begin = max(k_begin, (col0 >> 7) << 7);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -297,6 +303,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     p.b_slab = b_slab;
     p.a_nslab = 1;
     p.a_slab = 0;
+    p.tri = VG_TRI_NONE;
     p.tiles_m = (M + VG_BM - 1) / VG_BM;
     p.tiles_n = (N + VG_BN - 1) / VG_BN;
     p.tile_start = b->total_tiles;

@@ -28,7 +28,7 @@
 
 typedef double vg_td4 __attribute__((ext_vector_type(4)));
 
-#define VG_TRSM_MAXJOBS 12
+#define VG_TRSM_MAXJOBS 16
 struct VgTrsmArgs {
     VgTrsmJob job[VG_TRSM_MAXJOBS];
     int block_start[VG_TRSM_MAXJOBS + 1];
@@ -82,7 +82,8 @@ __device__ __forceinline__ void vg_trsm_strip(const VgTrsmJob& J, long c0, bool 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = b * 16 + fk + 4 * r;
-            rb[b][r] = (cok && row < m) ? Rg[(long)row * J.r_sk + col * J.r_sc] : 0.0;
+            if (J.rhs_ident) rb[b][r] = (cok && row < m && row == col) ? 1.0 : 0.0;
+            else rb[b][r] = (cok && row < m) ? Rg[(long)row * J.r_sk + col * J.r_sc] : 0.0;
             const int i = fi, k = fk + 4 * r;
             const bool in = b * 16 + i < m && b * 16 + k < m;
             dvb[b][r] = in ? Dg[(long)b * J.dinv_blk + (long)i * di + (long)k * dk] : (i == k ? 1.0 : 0.0);
@@ -205,8 +206,14 @@ hipError_t vg_trsm_launch(const VgTrsmJob* jobs, int njobs, hipStream_t st) {
 // ---- inverses of the 16 x 16 diagonal blocks of a lower-triangular matrix ------------------------------------------------
 // One wave per block: lane (i = lane & 15, c4 = lane >> 4) owns row i of columns 4 c4 .. 4 c4 + 3 of X = D^{-1}; forward
 // substitution row by row (x_i = (e_i - sum_{k<i} d_ik x_k) / d_ii), rows exchanged with wave shuffles.  Out: [nblk][16][16].
-__global__ __launch_bounds__(256) void vg_tri_diaginv_kernel(const double* __restrict__ L, long ldl, int m, double* __restrict__ out) {
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void vg_tri_diaginv_kernel(const double* __restrict__ L, long ldl, int m, double* __restrict__ out,
+                                                             const double* __restrict__ Lb, long ldlb, int mb, double* __restrict__ outb,
+                                                             int nblk_a) {
+    int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= nblk_a) {                        // second matrix of the launch
+        blk -= nblk_a; L = Lb; ldl = ldlb; m = mb; out = outb;
+        if (!L) return;
+    }
     if (blk * 16 >= m) return;
     const int lane = threadIdx.x & 63, i = lane & 15, c4 = lane >> 4;
     const int r0 = blk * 16;
@@ -232,8 +239,9 @@ __global__ __launch_bounds__(256) void vg_tri_diaginv_kernel(const double* __res
     for (int q = 0; q < 4; ++q) out[(long)blk * 256 + i * 16 + 4 * c4 + q] = x[q];
 }
 
-hipError_t vg_tri_diaginv_launch(const double* L, long ldl, int m, double* out, hipStream_t st) {
-    const int nblk = (m + 15) / 16;
-    hipLaunchKernelGGL(vg_tri_diaginv_kernel, dim3((nblk + 3) / 4), dim3(256), 0, st, L, ldl, m, out);
+hipError_t vg_tri_diaginv_launch(const double* L, long ldl, int m, double* out, hipStream_t st, const double* L2, long ldl2, int m2,
+                                 double* out2) {
+    const int nblk = (m + 15) / 16, nblk_a = ((nblk + 3) / 4) * 4, nblk2 = L2 ? (m2 + 15) / 16 : 0;
+    hipLaunchKernelGGL(vg_tri_diaginv_kernel, dim3((nblk_a + nblk2 + 3) / 4), dim3(256), 0, st, L, ldl, m, out, L2, ldl2, m2, out2, nblk_a);
     return hipGetLastError();
 }

@@ -46,19 +46,58 @@ def _basis_m(basis: str, g: np.ndarray) -> int:
 class Engine:
     """Owns a vggp_ctx.  See include/vggp.h for the contract of every call."""
 
-    def __init__(self, device: Optional[int] = None):
+    def __init__(self, device: Optional[int] = None, n_ranks: int = 1, rank: int = 0, unique_id: Optional[bytes] = None,
+                 allreduce=None):
+        """n_ranks > 1: this process is rank `rank` of a row-sharded job (one Engine per GPU).  `unique_id` (bytes from
+        Engine.unique_id() on rank 0, distributed by the host program) gives the context its RCCL communicator; or
+        `allreduce(numpy_view)` -- a Python function summing a float64 array over the ranks in place -- installs the host
+        callback transport (the multi-rank rehearsal on one GPU, where RCCL refuses duplicate devices)."""
         if not torch.cuda.is_available():
             raise RuntimeError("variational_gridded_gaussian_processes_amd needs a gfx950 GPU: "
                                "torch.cuda.is_available() is False and there is no CPU path")
         self.lib = _lib.load()
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        if unique_id is not None and len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.UNIQUE_ID_BYTES} bytes")
         h = C.c_void_p()
-        check(self.lib.vggp_create(C.byref(h), self.device_index))
+        uid = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES) if unique_id is not None else None
+        check(self.lib.vggp_create(C.byref(h), self.device_index, self.n_ranks, self.rank, C.cast(uid, C.c_void_p) if uid else None))
         self._h = h
+        self._cb = None
+        if allreduce is not None:
+            def _trampoline(_user, buf, count, fn=allreduce):
+                try:
+                    fn(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                    return 0
+                except Exception:          # never let a Python exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = _lib.ALLREDUCE_FN(_trampoline)          # keep the thunk alive as long as the context
+            check(self.lib.vggp_set_allreduce(self._h, self._cb, None))
         self.m1 = self.m2 = self.n1 = self.n2 = 0
         self.planned = False
         self.plan_token = 0          # bumped by every plan(): a model sharing this engine re-plans when it is not the last planner
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """RCCL unique id for Engine(..., n_ranks, rank, unique_id): call on rank 0, ship the bytes to the other ranks."""
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        check(_lib.load().vggp_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    @property
+    def transport(self) -> str:
+        t = C.c_int()
+        check(self.lib.vggp_comm_info(self._h, None, None, C.byref(t)))
+        return {0: "none", 1: "rccl", 2: "callback"}[t.value]
+
+    def allreduce(self, t: torch.Tensor) -> torch.Tensor:
+        """The context's sum all-reduce on a contiguous float64 GPU tensor, in place."""
+        check(self.lib.vggp_allreduce(self._h, _ptr(t), t.numel(), _stream(self.device)))
+        return t
 
     def close(self):
         if getattr(self, "_h", None):
