@@ -156,10 +156,13 @@ int vggp_elbo_partials(vggp_ctx* ctx, const double* Y, const double theta[5],
 int vggp_elbo_finish(vggp_ctx* ctx, const double* payload, double yy_total, const double theta[5],
                      double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 
-/* Masked / partially observed grid (BASELINE config 5).  Ym = W o Y and W (0/1 as float64) are DEVICE [n2][n1];
- * n_obs = sum(W), yy_obs = sum(Ym^2).  Phi = Kuf W Kuf^T is assembled in M-space (M = m1 m2 <= 8192) and factored
- * densely; value + analytic gradient as for vggp_elbo_step.  Replaces KroneckerStructure._elbo
- * (kronecker_structure.py:249-278) called with the observed subset of the grid as X, y.  Single rank. */
+/* Masked / partially observed grid (BASELINE config 5).  Ym = W o Y and W (0/1 as float64) are DEVICE [n2][n1] (this rank's
+ * row slab); n_obs = sum(W), yy_obs = sum(Ym^2) over ALL ranks.  Phi = Kuf W Kuf^T is assembled in M-space (M = m1 m2 <= 8192)
+ * and factored densely; value + analytic gradient as for vggp_elbo_step.  Replaces KroneckerStructure._elbo
+ * (kronecker_structure.py:249-278) called with the observed subset of the grid as X, y.
+ * Multi-rank context: every rank assembles the partial Phi_r (and its two lengthscale derivatives, the projections and a
+ * column statistic) of its rows, ONE all-reduce (3 M^2 + 3 M + n1 doubles) makes Sigma~ and its factorisation replicated,
+ * and a second all-reduce of 21 scalars closes the gradient terms that are sums over grid rows. */
 int vggp_elbo_step_masked(vggp_ctx* ctx, const double* Ym, const double* W, double n_obs, double yy_obs,
                           const double theta[5], double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 /* q(v) of the last masked step: mean and covariance diagonal, DEVICE [m1][m2]. */

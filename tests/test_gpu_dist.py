@@ -210,3 +210,71 @@ def test_rccl_transport_size_one(engine):
         assert abs(e_r - ref.elbo) <= 1e-8 * abs(ref.elbo) and np.abs(g_r - ref.grad).max() <= 1e-6 * np.abs(ref.grad).max()
         assert abs(e_r - e_s) <= 1e-12 * abs(e_s)
     eng.close()
+
+
+# ---- masked grids across ranks (BASELINE configs[4] names 8 GPUs) ------------------------------------------------------------
+MK_N1, MK_N2, MK_NK = 72, 60, 9          # B0 mesh with 8 x 8 cells: M = 64
+
+
+def _masked_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import dense as D
+    from variational_gridded_gaussian_processes_amd.sharded import make_engine, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, x1, x2 = D.gen_grid(MK_N1, MK_N2)
+        Wn = (np.random.default_rng(1).uniform(size=(MK_N2, MK_N1)) < 0.7).astype(np.float64)
+        rows = shard_rows(MK_N2, rank, world)
+        mesh = np.linspace(0, 1, MK_NK)
+        eng = make_engine(0, transport="gloo")
+        eng.plan("matern12", "b0", mesh, x1, "matern12", "b0", mesh, x2[rows], n_total=MK_N1 * MK_N2)
+        W = torch.tensor(Wn[rows], device="cuda:0")
+        Ym = torch.tensor(y.reshape(MK_N2, MK_N1)[rows], device="cuda:0") * W
+        yy = eng.sumsq(Ym)                       # summed over the ranks by the library
+        out = []
+        for k in range(3):
+            th = np.array(THETA) * (1.0 + 0.02 * k)
+            out.append(eng.elbo_step_masked(Ym, W, float(Wn.sum()), yy, th)[:2])
+        mean, var = eng.qv_masked()
+        xs = np.random.default_rng(3).uniform(0, 1, (40, 2))
+        pm, pv = eng.posterior_masked(torch.tensor(xs, device="cuda:0"))
+        q.put((rank, out, mean.cpu().numpy(), var.cpu().numpy(), pm.cpu().numpy(), pv.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_masked_step_sharded_over_ranks(engine, world):
+    """Config 5's split: every rank assembles the partial Phi_r of its grid rows, ONE all-reduce (3 M^2 + 3 M + n1 doubles),
+    replicated dense factorisation, a second all-reduce of the row-sum scalars; equals the masked oracle on the full grid."""
+    from oracle import dense as D, kron as Kr
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000) + world
+    procs = [ctx.Process(target=_masked_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    X, y, x1, x2 = D.gen_grid(MK_N1, MK_N2)
+    Wn = (np.random.default_rng(1).uniform(size=(MK_N2, MK_N1)) < 0.7).astype(np.float64)
+    mesh = np.linspace(0, 1, MK_NK)
+    f1, f2 = Kr.Factor("b0", "matern12", mesh, x1), Kr.Factor("b0", "matern12", mesh, x2)
+    for k in range(3):
+        ref = Kr.elbo_step_masked(y.reshape(MK_N2, MK_N1), Wn, f1, f2, np.array(THETA) * (1.0 + 0.02 * k))
+        for rank, out, *_ in res:
+            e, g = out[k]
+            assert abs(e - ref.elbo) <= 1e-9 * abs(ref.elbo), (k, rank)
+            assert np.abs(g - ref.grad).max() <= 1e-7 * np.abs(ref.grad).max(), (k, rank)
+        assert all(r[1][k][0] == res[0][1][k][0] for r in res)
+    rm, rv = Kr.q_v_masked(ref)
+    xs = np.random.default_rng(3).uniform(0, 1, (40, 2))
+    om, ov = Kr.posterior_masked(ref, f1, f2, xs)
+    for _, _, mean, var, pm, pv in res:
+        assert np.abs(mean - rm).max() <= 1e-7 * np.abs(rm).max() and np.abs(var - rv).max() <= 1e-7 * np.abs(rv).max()
+        assert np.abs(pm - om).max() <= 1e-7 * np.abs(om).max() and np.abs(pv - ov).max() <= 1e-6 * np.abs(ov).max()

@@ -130,14 +130,21 @@ __global__ __launch_bounds__(256) void vgm_red_kernel(const VgmRedArgs A) {
 enum { RJ_LOGDET = 0, RJ_Q, RJ_AA, RJ_TRS, RJ_TRPHI, RJ_MK1PTS, RJ_TRMK1, RJ_SPHI1, RJ_AC1, RJ_MKA1, RJ_Z1, RJ_HV1, RJ_MK1PT,
        RJ_MK2PTS, RJ_TRMK2, RJ_SPHI2, RJ_AC2, RJ_MKA2, RJ_Z2, RJ_HV2, RJ_MK2PT, RJ_COUNT };
 
-struct VgmFinalArgs { const double* theta; const double* partial; double* out; double N, yy; int m1, m2; };
+// partial[job][VG_MD_NPART] -> scal[job].  Row-sharded step: the sums over this rank's grid rows (local_mask bit set) add up
+// over the ranks; every other scalar is computed identically on every rank from all-reduced inputs, so only rank 0
+// contributes it to the second (tiny) all-reduce -- exact, and all ranks end up with identical scalars.
+__global__ void vgm_sum_kernel(const double* partial, double* scal, unsigned local_mask, int keep_replicated) {
+    const int j = threadIdx.x;
+    if (j >= RJ_COUNT) return;
+    double s = 0.0;
+    for (int k = 0; k < VG_MD_NPART; ++k) s += partial[j * VG_MD_NPART + k];
+    scal[j] = (((local_mask >> j) & 1u) || keep_replicated) ? s : 0.0;
+}
+
+struct VgmFinalArgs { const double* theta; const double* scal; double* out; double N, yy; int m1, m2; };
 __global__ void vgm_final_kernel(const VgmFinalArgs A) {
     __shared__ double S[RJ_COUNT];
-    if (threadIdx.x < RJ_COUNT) {
-        double s = 0.0;
-        for (int k = 0; k < VG_MD_NPART; ++k) s += A.partial[threadIdx.x * VG_MD_NPART + k];
-        S[threadIdx.x] = s;
-    }
+    if (threadIdx.x < RJ_COUNT) S[threadIdx.x] = A.scal[threadIdx.x];
     __syncthreads();
     if (threadIdx.x != 0) return;
     const double s1 = A.theta[2], s2 = A.theta[3], v = A.theta[4], N = A.N, yy = A.yy;
@@ -194,6 +201,9 @@ struct VgMasked {
     double *nb1, *nb2, *hv1, *hv2, *wn1, *wn2, *PT1, *PT2, *PTS1, *PTS2, *MkA1, *MkA2, *a0, *partial, *out;
     double *cholscratch, *choljit;
     int* cholstatus;
+    // the all-reduce buffer of the row-sharded masked step: [slack 2 m2^2 | C, C1, C2 (3 M) | wn2 (n1) | R3 (3 M^2)];
+    // the collective covers everything after the slack (vg_partials_enqueue leaves G2, H2 in it, which this path ignores)
+    double *mpay, *R3, *scal;
     void* mem = nullptr;
     size_t bytes = 0;
 };
@@ -212,7 +222,11 @@ static void vgm_layout(VgMasked& w, char* base, size_t& off) {
     w.T = take(n1 * m2 * m2); w.Tv = take(n1 * m2 * m2);
     w.UB = take(m1 * n2); w.UV = take(m1 * n2); w.Zb = take(n1 * n2); w.Zv1 = take(n1 * n2); w.Zv2 = take(n1 * n2);
     w.B1s = take(m1 * n1); w.B2s = take(m2 * n2);
-    w.nb1 = take(n1); w.nb2 = take(n2); w.hv1 = take(n1); w.hv2 = take(n2); w.wn1 = take(n2); w.wn2 = take(n1);
+    w.nb1 = take(n1); w.nb2 = take(n2); w.hv1 = take(n1); w.hv2 = take(n2); w.wn1 = take(n2);
+    w.mpay = take(2 * m2 * m2 + 3 * M + n1 + 3 * MM);
+    w.wn2 = base ? w.mpay + 2 * m2 * m2 + 3 * M : nullptr;
+    w.R3 = base ? w.wn2 + n1 : nullptr;
+    w.scal = take(32);
     w.PT1 = take(m1 * m1); w.PT2 = take(m2 * m2); w.PTS1 = take(m1 * m1); w.PTS2 = take(m2 * m2);
     w.MkA1 = take(M); w.MkA2 = take(M); w.a0 = take(M);
     w.partial = take(VG_MD_MAXJOBS * VG_MD_NPART); w.out = take(8);
@@ -318,11 +332,14 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     int rc = vgm_prepare(c);
     if (rc) return rc;
     VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
-    // factor build, Cholesky, B|V, Mk and the projections C, C1, C2 of the masked observations (unit outputscale)
-    if ((rc = vg_partials_enqueue(c, Ym, c->payload, st))) return rc;
+    // factor build, Cholesky, B|V, Mk and the projections C, C1, C2 of the masked observations (unit outputscale).
+    // Row-sharded job (n_ranks > 1): Ym, W are this rank's row slab; every sum over grid rows below is a PARTIAL sum that
+    // lands in the all-reduce buffer w.mpay (C, C1, C2 | wn2 | the three M x M assembly matrices) -- ONE collective --
+    // after which Sigma~, its factorisation and a0 are replicated on every rank.
+    if ((rc = vg_partials_enqueue(c, Ym, w.mpay, st))) return rc;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     const double *B1 = d1.BV, *V1 = d1.BV + m1 * n1, *B2 = d2.BV, *V2 = d2.BV + m2 * n2;
-    const double *C0 = c->payload + 2 * m2 * m2, *C1 = C0 + M, *C2 = C1 + M;
+    const double *C0 = w.mpay + 2 * m2 * m2, *C1 = C0 + M, *C2 = C1 + M;
 
     // column statistics
     VGM_LAUNCH1D(vgm_coldot_kernel, n1, st, B1, B1, (int)m1, n1, w.nb1);
@@ -334,10 +351,10 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
         const int nslab = (int)(mm < 64 ? mm : 64);
         hipLaunchKernelGGL(vgm_wcol_part_kernel, dim3((unsigned)((n1 + 255) / 256), (unsigned)nslab), dim3(256), 0, st, W, w.nb2,
                            n1, n2, nslab, w.T);
-        VGM_LAUNCH1D(vgm_wcol_sum_kernel, n1, st, w.T, n1, nslab, w.wn2);
+        VGM_LAUNCH1D(vgm_wcol_sum_kernel, n1, st, w.T, n1, nslab, w.wn2);           // partial over this rank's rows
     }
     hipLaunchKernelGGL(vgm_wrow_kernel, dim3((unsigned)n2), dim3(256), 0, st, W, w.nb1, n1, n2, w.wn1);
-    // assembly
+    // assembly (partial over this rank's rows: T sums over j, R = PP1 T is linear in T)
     VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * n2, st, B2, B2, (int)m2, (int)m2, n2, w.PP2);
     VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * n2, st, B2, V2, (int)m2, (int)m2, n2, w.PP2v);
     VGM_LAUNCH1D(vgm_pairprod_kernel, m1 * m1 * n1, st, B1, B1, (int)m1, (int)m1, n1, w.PP1);
@@ -345,12 +362,14 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     VG_HIP(hipGetLastError());
     if ((rc = gemm1(W, 1, n1, w.PP2, 1, n2, w.T, (int)(m2 * m2), (int)n1, (int)(m2 * m2), (int)n2, st))) return rc;
     if ((rc = gemm1(W, 1, n1, w.PP2v, 1, n2, w.Tv, (int)(m2 * m2), (int)n1, (int)(m2 * m2), (int)n2, st))) return rc;
-    if ((rc = gemm1(w.PP1, n1, 1, w.T, m2 * m2, 1, w.R, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)n1, st))) return rc;
-    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R, (int)m1, (int)m2, c->theta, 1, w.Sg);
-    if ((rc = gemm1(w.PP1v, n1, 1, w.T, m2 * m2, 1, w.R, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)n1, st))) return rc;
-    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R, (int)m1, (int)m2, c->theta, 0, w.Phip);
-    if ((rc = gemm1(w.PP1, n1, 1, w.Tv, m2 * m2, 1, w.R, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)n1, st))) return rc;
-    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R, (int)m1, (int)m2, c->theta, 0, w.Phip + M * M);
+    if ((rc = gemm1(w.PP1, n1, 1, w.T, m2 * m2, 1, w.R3, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)n1, st))) return rc;
+    if ((rc = gemm1(w.PP1v, n1, 1, w.T, m2 * m2, 1, w.R3 + M * M, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)n1, st))) return rc;
+    if ((rc = gemm1(w.PP1, n1, 1, w.Tv, m2 * m2, 1, w.R3 + 2 * M * M, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)n1, st))) return rc;
+    // the collective of the masked step (no-op on a single-rank context)
+    if ((rc = vg_allreduce(c, w.mpay + 2 * m2 * m2, 3 * M + n1 + 3 * M * M, st))) return rc;
+    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3, (int)m1, (int)m2, c->theta, 1, w.Sg);
+    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3 + M * M, (int)m1, (int)m2, c->theta, 0, w.Phip);
+    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3 + 2 * M * M, (int)m1, (int)m2, c->theta, 0, w.Phip + M * M);
     // dense factorisation and inverse of Sigma~
     if ((rc = dense_chol_inverse(c, w, st))) return rc;
     // a0 = Sinv c0 ; A0 = mat(a0) (m1 x m2)
@@ -399,7 +418,12 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     job(RJ_HV2, w.hv2, w.wn1, n2, 1, 1, 0);
     job(RJ_MK2PT, d2.Mk, w.PT2, m2 * m2, 1, 1, 0);
     hipLaunchKernelGGL(vgm_red_kernel, dim3(VG_MD_NPART, RJ_COUNT), dim3(256), 0, st, ra);
-    VgmFinalArgs fa{c->theta, w.partial, w.out, n_obs, yy_obs, (int)m1, (int)m2};
+    // scalars that are sums over this rank's grid rows (everything else is replicated): second, tiny collective
+    const unsigned local_mask = (1u << RJ_Z1) | (1u << RJ_Z2) | (1u << RJ_HV2) | (1u << RJ_MK2PT);
+    const bool multi = c->n_ranks > 1 || c->comm || c->cb;
+    hipLaunchKernelGGL(vgm_sum_kernel, dim3(1), dim3(64), 0, st, w.partial, w.scal, local_mask, (!multi || c->rank == 0) ? 1 : 0);
+    if ((rc = vg_allreduce(c, w.scal, RJ_COUNT, st))) return rc;
+    VgmFinalArgs fa{c->theta, w.scal, w.out, n_obs, yy_obs, (int)m1, (int)m2};
     hipLaunchKernelGGL(vgm_final_kernel, dim3(1), dim3(64), 0, st, fa);
     VG_HIP(hipGetLastError());
     // readback
