@@ -8,18 +8,25 @@ iteration of the notebooks' fit loop (5_gridded_kronecker_structure_models.ipynb
 hyper-parameters therefore change every step (the eigensolver's warm start is real work, not a
 cached answer).  Observations are resident in HBM before the timed region.
 
-N > 1 (weak scaling): every rank owns a 1024-row slab of a (1024*N) x 1024 grid (rows of Y =
-dimension 2); the packed payload {G2,H2,C,C1,C2} is summed with ONE all-reduce (RCCL) per step.
+N > 1 (weak scaling): every rank owns an (n2_local x n1) slab of an (n2_local*N) x n1 grid (rows of Y = dimension 2); the
+step of the multi-rank context is  partials -> ONE all-reduce of the packed payload {G2,H2,C,C1,C2} (RCCL communicator
+owned by the library, csrc/comm.hip) -> finish.  BASELINE configs[3] is `--gpus 4 --n1 4096 --n2-local 1024`;
+configs[4] (masked grid) is `--masked --n1 2048 --n2-local 2048 --m 32` (divide --n2-local by the rank count).
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
-  roofline      live HIP-event timing of the dominant launch group vs the gfx950 roofline
-  stages_us     per-launch-group breakdown of one step (HIP events on the launch stream)
-  kron_solve    BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
-  cpu_baseline  oracle/kron.py (the structured CPU twin, "port") timed on the host cores
+  roofline          live HIP-event timing of the projection launch (the only pass over Y) vs the gfx950 fp64 MFMA roofline;
+                    `traffic` = PMC bytes of the committed rocprofv3 passes, only while they match the kernel source at HEAD
+  stages_us         per-launch-group breakdown of one step (HIP events on the launch stream, plain launches)
+  cold_ms_per_step  the same loop with the eigensolver's warm start off
+  m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
+  kron_solve        BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
+  factor_build      HBM-write rate of the factor kernel at m = n = 8192
+  cpu_baseline      oracle/kron.py (the structured CPU twin, "port") timed on the host cores
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector == matrix peak
 HBM_PEAK_GBS = 8000.0
+PROJ = "gemm_project(S=[B2;V2]Y)"
 
 
 def softplus(x):
@@ -64,7 +72,13 @@ def theta_from_raw(raw):
     return th
 
 
-PROJ = "gemm_project(S=[B2;V2]Y)"
+THETA0 = np.array([0.2, 0.2, 1.0, 1.0, 0.05 ** 2])
+
+
+def raw_start():
+    raw0 = THETA0.copy()
+    raw0[4] -= 1e-4
+    return inv_softplus(raw0)
 
 
 def algorithmic_flops(n1, n2, m1, m2):
@@ -130,6 +144,32 @@ def dense_literal_timing(kind, theta):
         return {"error": str(e)}
 
 
+def source_sha():
+    """Identity of the projection kernel's source: PMC traffic numbers are only reported while they were collected on this."""
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "common.h"):
+        with open(os.path.join(ROOT, "variational_gridded_gaussian_processes_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(n1, n2_loc, m):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    runs of this same command, profiles/r2_pmc_traffic.json written by tools/pmc_traffic.py).  None -- and the reason -- when
+    the passes are absent, were taken on another kernel source than HEAD's, or on another launch shape."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception:
+        return None, "no committed PMC passes (profiles/r2_pmc_traffic.json)"
+    if d.get("source_sha") != source_sha():
+        return None, f"stale: passes taken on kernel source {d.get('source_sha')}, HEAD is {source_sha()}"
+    if d.get("shape") != [n1, n2_loc, m]:
+        return None, f"passes taken on shape {d.get('shape')}"
+    return d, "profiles/r2_pmc_traffic.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,14 +179,21 @@ def main():
     ap.add_argument("--n1", type=int, default=None, help="grid points along dimension 1 (the fast axis of Y; not sharded)")
     ap.add_argument("--n2-local", type=int, default=None, help="grid rows (dimension 2) per rank: BASELINE configs[3] is "
                                                               "--gpus 4 --n1 4096 --n2-local 1024")
-    ap.add_argument("--no-extras", action="store_true", help="skip cold_ms_per_step / m_d_sweep / kron_solve")
-    ap.add_argument("--m", type=int, default=128, help="inducing points per dimension")
+    ap.add_argument("--m", type=int, default=128, help="inducing points (or B0 cells) per dimension")
     ap.add_argument("--kind", default="rbf")
+    ap.add_argument("--masked", action="store_true", help="BASELINE configs[4]: Bernoulli(0.7) mask, B0 cells, masked step")
     ap.add_argument("--cold", action="store_true", help="disable the eigensolver warm start")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of N>1 ranks "
-                                                      "sharing one GPU; never a reported number)")
+    ap.add_argument("--no-extras", action="store_true", help="skip cold_ms_per_step / m_d_sweep / kron_solve / factor_build")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL communicator owned by the library, the measured path) | "
+                                                      "gloo (rehearsal of N>1 ranks sharing one GPU; never a reported number)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: native libraries (gloo's "[Gloo] Rank 0 is connected ..." banner, RCCL
+    # notices) print to file descriptor 1, so everything else is sent to stderr for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -154,23 +201,45 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from variational_gridded_gaussian_processes_amd import Engine
+    from variational_gridded_gaussian_processes_amd.sharded import ExternalCollectiveStep, make_engine
+    from oracle import dense as D      # synthetic-data generator only (gen_2d layout + the notebooks' latent function)
+
+    collective = "none"
+    ext = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # torch.distributed only bootstraps (unique id, barriers, the max over ranks of the wall time): gloo on the CPU.  The
+        # data path is the library's own RCCL communicator.
+        dist.init_process_group("gloo")
+        dev = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev)
         if args.backend == "gloo":
-            local_rank = local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo")
+            eng = make_engine(dev, transport="gloo")
+            collective = "host callback over gloo (rehearsal)"
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            ok, eng = 1, None
+            try:
+                eng = make_engine(dev, transport="rccl")
+            except Exception as e:           # all ranks must agree on the fallback
+                print(f"[rank {rank}] library RCCL communicator failed: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                collective = "RCCL communicator owned by libvggp_hip.so (ncclAllReduce on the step's stream)"
+            else:                            # torch.distributed carries the all-reduce between the two halves of the step
+                if eng is not None:
+                    eng.close()
+                eng = Engine(dev)
+                ext = ExternalCollectiveStep(eng, dist.new_group(backend="nccl"))
+                collective = "torch.distributed NCCL all_reduce between vggp_elbo_partials / vggp_elbo_finish (fallback)"
     else:
         torch.cuda.set_device(0)
+        eng = Engine(0)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
-    from variational_gridded_gaussian_processes_amd import Engine
-    from oracle import dense as D      # synthetic-data generator only (gen_2d layout + the notebooks' latent function)
 
     n1 = args.n1 if args.n1 is not None else args.n
     n2_loc = args.n2_local if args.n2_local is not None else args.n
@@ -181,28 +250,32 @@ def main():
     del X
     Yg = y.reshape(n2_glob, n1)
     sl = slice(rank * n2_loc, (rank + 1) * n2_loc)
-    g1 = np.linspace(0, 1, m)
-    g2 = np.linspace(0, float(world), m)
-    eng = Engine(local_rank if world > 1 else 0)
-    eng.plan(args.kind, "points", g1, x1, args.kind, "points", g2, x2[sl], n_total=n1 * n2_glob,
-             warm_start=not args.cold)
+    basis = "b0" if args.masked else "points"
+    kind = "matern12" if args.masked else args.kind
+    g1 = np.linspace(0, 1, m + 1 if args.masked else m)
+    g2 = np.linspace(0, float(world), m + 1 if args.masked else m)
+    eng.plan(kind, basis, g1, x1, kind, basis, g2, x2[sl], n_total=n1 * n2_glob, warm_start=not args.cold)
     Y = torch.tensor(Yg[sl], device=eng.device)
-    yy = float((Yg * Yg).sum())
-    theta0 = np.array([0.2, 0.2, 1.0, 1.0, 0.05 ** 2])
-    raw0 = theta0.copy()
-    raw0[4] -= 1e-4
-    raw0 = inv_softplus(raw0)
-    opt = Adam(raw0, lr=0.01)
-    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep
-    sharded = ShardedStep(eng) if world > 1 else None     # partials -> ONE all-reduce (RCCL) -> finish, on one stream
+    n_points = n1 * n2_glob
+    W, n_obs, Wg = None, 0.0, 1.0
+    if args.masked:
+        Wg = (np.random.default_rng(1).uniform(size=(n2_glob, n1)) < 0.7).astype(np.float64)
+        W = torch.tensor(Wg[sl], device=eng.device)
+        Y = Y * W
+        n_obs = float(Wg.sum())
+        n_points = n_obs
+    yy = float((Yg * Yg * Wg).sum())
+    opt = Adam(raw_start(), lr=0.01)
 
     def one_step():
         raw = opt.x
         th = theta_from_raw(raw.copy())
-        if world > 1:
-            elbo, g, info = sharded.step(Y, yy, th)
+        if args.masked:
+            elbo, g, info = eng.elbo_step_masked(Y, W, n_obs, yy, th)
+        elif ext is not None:
+            elbo, g, info = ext.step(Y, yy, th)
         else:
-            elbo, g, info = eng.elbo_step(Y, yy, th)
+            elbo, g, info = eng.elbo_step(Y, yy, th)       # multi-rank context: partials -> all-reduce -> finish inside
         graw = g / (1.0 + np.exp(-raw))              # softplus chain rule
         opt.step(-graw)
         return elbo, info
@@ -221,83 +294,132 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
 
-    # live per-launch-group timing (HIP events on the launch stream), separate short loop
-    eng.profile(True)
-    nprof = max(5, min(50, args.steps))
-    for _ in range(nprof):
-        one_step()
-    stage_ms, psteps = eng.profile_read()
-    eng.profile(False)
-    stages_us = {k: v / max(psteps, 1) * 1e3 for k, v in stage_ms.items()}
+    # live per-launch-group timing (HIP events on the launch stream, plain launches), separate short loop
+    stages_us = {}
+    if not args.masked:
+        eng.profile(True)
+        nprof = max(5, min(50, args.steps))
+        for _ in range(nprof):
+            one_step()
+        stage_ms, psteps = eng.profile_read()
+        eng.profile(False)
+        stages_us = {k: v / max(psteps, 1) * 1e3 for k, v in stage_ms.items() if v > 0.0}
 
     out = None
     if rank == 0:
-        flops = algorithmic_flops(n1, n2_loc, m, m)
-        dom = max(stages_us, key=stages_us.get)
-        proj = PROJ
-        proj_tflops = flops[proj] / (stages_us[proj] * 1e-6) / 1e12
-        step_flops = sum(flops.values())
-        roofline = {
-            "kernel": "vg_gemm_gram_project_kernel (launch group '%s': the only pass over Y)" % proj,
-            "bound": "mfma", "achieved": proj_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": proj_tflops / FP64_PEAK_TFLOPS,
-            "traffic": (pmc_traffic() or {}).get("bytes"),        # HBM bytes per launch (PMC passes, see traffic_source)
-            "traffic_source": pmc_traffic(),
-            "flops_per_launch": flops[proj], "avg_launch_us": stages_us[proj],
-            # algorithmic bytes of that launch: Y once, [B2;V2] once, the un-split output S
-            "algorithmic_bytes_per_launch": 8 * (n1 * n2_loc + 2 * m * n2_loc + 2 * m * n1),
-            "dominant_stage_by_time": dom, "dominant_stage_us": stages_us[dom],
-            "step_dense_flops": step_flops,
-            "step_frac_of_fp64_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            "step_hbm_floor_bytes": 8 * n1 * n2_loc + 8 * 2 * 2 * (m * n1 + m * n2_loc) + 8 * 4 * m * m,
-        }
-        # BASELINE metric (ii): Kronecker solve
-        ks = kron_solve_bench(eng, 1024)
         out = {
             "metric": "ELBO-step grid-points/sec (value + 5-component gradient), 1024x1024 RBF grid per GPU",
-            "value": n1 * n2_glob / (ms_per_step * 1e-3), "unit": "grid-points/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "value": n_points / (ms_per_step * 1e-3), "unit": "grid-points/s" if not args.masked else "observed grid-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"2D Kronecker {args.kind} GP (points basis), {n2_glob}x{n1} grid "
-                                   f"({n2_loc}x{n1} per GPU), m_d={m}, Adam fit loop (lr 0.01), "
-                                   f"eigensolver warm start {'off' if args.cold else 'on'}",
-                       "parallelism": f"grid rows sharded over {world} rank(s), one all-reduce of "
-                                      f"{eng.payload_len} doubles per step" if world > 1 else "single GPU"},
-            "elbo_last": elbo, "jacobi": {"sweeps": info["sweeps"], "rounds": info["rounds"], "jitter": info["jitter"],
-                                           "polished": info.get("polished")},
-            "roofline": roofline, "stages_us": stages_us, "kron_solve": ks,
+            "config": {"workload": (f"2D Kronecker {kind} GP ({'B0 cells, 30 % of the grid masked out' if args.masked else 'points basis'}), "
+                                    f"{n2_glob}x{n1} grid ({n2_loc}x{n1} per GPU), m_d={m}, Adam fit loop (lr 0.01), "
+                                    f"eigensolver warm start {'off' if args.cold else 'on'}"),
+                       "parallelism": (f"grid rows sharded over {world} rank(s), one all-reduce of {eng.payload_len} doubles per "
+                                       f"step: {collective}") if world > 1 else "single GPU"},
+            "elbo_last": elbo,
+            "jacobi": {"sweeps": info["sweeps"], "rounds": info["rounds"], "jitter": info["jitter"], "polished": info.get("polished")},
+            "stages_us": stages_us,
         }
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n1, n2_loc, m, args.kind, theta0)
+        if not args.masked:
+            flops = algorithmic_flops(n1, n2_loc, m, m)
+            dom = max(stages_us, key=stages_us.get)
+            proj_tflops = flops[PROJ] / (stages_us[PROJ] * 1e-6) / 1e12
+            step_flops = sum(flops.values())
+            alg_bytes = 8 * (n1 * n2_loc + 2 * m * n2_loc + 2 * m * n1)       # Y once, [B2;V2] once, the un-split output S
+            tr, tr_src = pmc_traffic(n1, n2_loc, m)
+            out["roofline"] = {
+                "kernel": f"{eng.project_kernel_name()} (launch group '{PROJ}': the only pass over Y)",
+                "bound": "mfma", "achieved": proj_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": proj_tflops / FP64_PEAK_TFLOPS,
+                "traffic": tr["bytes"] if tr else None, "traffic_source": tr_src, "traffic_detail": tr,
+                "flops_per_launch": flops[PROJ], "avg_launch_us": stages_us[PROJ],
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_over_algorithmic": (tr["bytes"] / alg_bytes) if tr else None,
+                "dominant_stage_by_time": dom, "dominant_stage_us": stages_us[dom],
+                "step_dense_flops": step_flops,
+                "step_frac_of_fp64_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "step_hbm_floor_bytes": 8 * n1 * n2_loc + 8 * 2 * 2 * (m * n1 + m * n2_loc) + 8 * 4 * m * m,
+            }
+        if world == 1 and not args.no_extras and not args.masked:
+            out["cold_ms_per_step"] = timed_loop(eng, Y, yy, args.kind, x1, x2, m, warm=False, steps=40, warmup=5)
+            out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=40 if md < 256 else 12,
+                                                    warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
+            out["kron_solve"] = kron_solve_bench(eng, 1024)
+            out["factor_build"] = factor_build_bench(eng)
+        if not args.no_cpu and world == 1 and not args.masked:
+            out["cpu_baseline"] = cpu_baseline(n1, n2_loc, m, args.kind, THETA0)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    runs of this same command, profiles/r1_pmc_traffic.json written by tools/pmc_traffic.py); None when absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except Exception:
-        return None
+def timed_loop(eng, Y, yy, kind, x1, x2, m, warm, steps, warmup):
+    """ms per step of the same Adam fit loop with another plan (inducing count / warm start) on the same data."""
+    import torch
+    g = np.linspace(0, 1, m)
+    eng.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=warm)
+    opt = Adam(raw_start(), lr=0.01)
+
+    def one():
+        raw = opt.x
+        e, gr, info = eng.elbo_step(Y, yy, theta_from_raw(raw.copy()))
+        opt.step(-(gr / (1.0 + np.exp(-raw))))
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def factor_build_bench(eng, n=8192, reps=5):
+    """North-star evidence for the kernel build: HBM-write rate of vg_factor_kernel at m = n = 8192 (outside the cache regime:
+    2.1 GB of outputs), pairwise RBF factors and B0 cell integrals.  Algorithmic bytes = 16 B per output element (value +
+    d/d ell) for the m x n and the m x m matrix.  (The rocprofv3 kernel-trace figure of the same launch is in profiles/.)"""
+    import torch
+    from variational_gridded_gaussian_processes_amd._lib import BASIS, KIND, check
+    res = {}
+    o = dict(dtype=torch.float64, device=eng.device)
+    x = torch.linspace(0, 1, n, **o)
+    A, dA, K, dK = torch.empty(n, n, **o), torch.empty(n, n, **o), torch.empty(n, n, **o), torch.empty(n, n, **o)
+    for kind, basis in (("rbf", "points"), ("matern12", "b0")):
+        g = torch.linspace(0, 1, n + 1 if basis == "b0" else n, **o)
+
+        def call():
+            check(eng.lib.vggp_factor_build(eng._h, KIND[kind], BASIS[basis], x.data_ptr(), n, g.data_ptr(), n, 0.2, 0,
+                                            A.data_ptr(), dA.data_ptr(), K.data_ptr(), dK.data_ptr(), 0))
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        byt = 2 * 16.0 * n * n
+        res[f"{kind}_{basis}"] = {"ms": dt * 1e3, "GB/s_written": byt / dt / 1e9, "frac_of_hbm_peak": byt / dt / 1e9 / HBM_PEAK_GBS}
+    res["n"] = n
+    res["algorithmic_bytes"] = 2 * 16 * n * n
+    return res
 
 
 def kron_solve_bench(eng, n, reps=20):
     """BASELINE metric (ii): X = K1^{-1} Y K2^{-T} FROM THE CHOLESKY FACTORS (nothing pre-inverted: the whole solve --
-    diagonal-block inverses, four blocked triangular solves -- is inside the timed region).  Algorithmic bytes and flops as
-    SURVEY.md section 8d defines them: 16 n1 n2 + 4 (n1^2 + n2^2) bytes, 2 n1^2 n2 + 2 n2^2 n1 flops (four triangular solves)."""
+    diagonal-block inverses, block-doubling inverse, four triangular-aware GEMMs -- is inside the timed region).  Algorithmic
+    bytes and flops as SURVEY.md section 8d defines them: 16 n1 n2 + 4 (n1^2 + n2^2) bytes, 2 n1^2 n2 + 2 n2^2 n1 flops."""
     import torch
     from oracle import kron as Kr
     z = np.linspace(0, 1, n)
@@ -319,7 +441,7 @@ def kron_solve_bench(eng, n, reps=20):
     flops = 4 * n ** 3
     return {"n": n, "ms": dt * 1e3, "GB/s": alg_bytes / dt / 1e9, "algorithmic_bytes": alg_bytes,
             "TFLOP/s_algorithmic(4n^3)": flops / dt / 1e12, "frac_of_fp64_peak": flops / dt / 1e12 / FP64_PEAK_TFLOPS,
-            "from": "Cholesky factors (substitution; no factor is inverted)", "max_abs_residual": resid}
+            "from": "Cholesky factors (timed region includes everything)", "max_abs_residual": resid}
 
 
 if __name__ == "__main__":

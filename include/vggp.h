@@ -248,6 +248,8 @@ int vggp_kron_solve(vggp_ctx* ctx, const double* L1, int64_t n1, const double* L
 int         vggp_profile(vggp_ctx* ctx, int enable);
 int         vggp_profile_read(vggp_ctx* ctx, double ms_out[VGGP_NSTAGE], int32_t* steps_out, int reset);
 const char* vggp_stage_name(int stage);
+/* Name of the kernel the last projection launch (S = [B2;V2] Y, the only pass over Y) dispatched: the roofline kernel. */
+const char* vggp_project_kernel_name(void);
 
 /* sum of squares of a DEVICE array, summed over all ranks of the context (yy_total); result to HOST. */
 int vggp_sumsq(vggp_ctx* ctx, const double* y, int64_t n, double* out, void* stream);

@@ -1,7 +1,7 @@
 """Per-kernel timeline of ONE steady-state ELBO step from a rocprofv3 --kernel-trace CSV (graph replay):
 start offsets, durations and the idle gaps between consecutive kernels.  usage: trace_step.py <dir>"""
 import csv, glob, os, sys
-f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
+f = sys.argv[1] if sys.argv[1].endswith(".csv") else glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("vg_")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts with vg_factor_kernel; take the median-length step among the last 50

@@ -73,6 +73,7 @@ SYMBOLS = {
     "vggp_profile": (_I, [_P, _I]),
     "vggp_profile_read": (_I, [_P, C.POINTER(_D), C.POINTER(C.c_int32), _I]),
     "vggp_stage_name": (C.c_char_p, [_I]),
+    "vggp_project_kernel_name": (C.c_char_p, []),
 }
 
 _lib = None

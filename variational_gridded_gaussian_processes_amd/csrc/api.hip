@@ -1452,6 +1452,8 @@ extern "C" int vggp_debug_read_misc(vggp_ctx* c, void* host, int64_t bytes) {
     return VGGP_OK;
 }
 
+extern "C" const char* vggp_project_kernel_name(void) { return vg_last_project_kernel(); }
+
 extern "C" int vggp_profile(vggp_ctx* c, int enable) {
     if (!c) { vg_set_error("null context"); return VGGP_EINVAL; }
     VG_ENTER_DEVICE(c->device);

@@ -85,6 +85,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
                 int b_nslab = 1, long b_slab = 0, double alpha = 1.0, int accum = 0);
 #define VG_GEMM_TAG_GRAM_PROJECT 1
 hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag = 0);
+const char* vg_last_project_kernel();      // name of the kernel the last VG_GEMM_TAG_GRAM_PROJECT launch dispatched
 
 // segment reduction: out[i] = sum_s in[s*slab + i]
 #define VG_RED_MAXSEG 8

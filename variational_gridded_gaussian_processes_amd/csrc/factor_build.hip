@@ -263,6 +263,33 @@ __global__ __launch_bounds__(256) void vg_factor_kernel(const VgFactorArgs2 args
         }
         return;
     }
+    if (J.basis == VGGP_BASIS_B0 && kpart && !(J.flags & VGGP_FLAG_B0_F32_KDELTA)) {
+        // Toeplitz in kd = |k - p| (vg_b0_K): everything but e^{-kd t} is a constant of the launch -- one exponential per element
+        const double t = (J.grid[1] - J.grid[0]) / ell, sh = sinh(0.5 * t), s4 = 4.0 * sh * sh, sh2 = 2.0 * sinh(t);
+        const double em1 = expm1(-t), l2 = ell * ell, toe = t / ell;
+        const double v_diag = l2 * 2.0 * (em1 + t), d_diag = 2.0 * ell * 2.0 * (em1 + t) + l2 * (2.0 * toe) * em1;
+        auto el = [&](int kd, double& v, double& dv) {
+            const double e = exp(-(double)kd * t), r = e * s4, dr = toe * e * ((double)kd * s4 - sh2);
+            v = kd ? l2 * r : v_diag;
+            dv = kd ? 2.0 * ell * r + l2 * dr : d_diag;
+        };
+        for (int r = 0; r < tmw; ++r) {
+            const int k = row0 + rw0 + r;
+            if (k >= m) break;
+            double v0, d0, v1, d1;
+            el(k > c ? k - c : c - k, v0, d0);
+            el(k > c + 1 ? k - c - 1 : c + 1 - k, v1, d1);
+            const long o = (long)k * ncols + c;
+            if (vec) {
+                if (O) *reinterpret_cast<double2*>(O + o) = make_double2(v0, v1);
+                if (dO) *reinterpret_cast<double2*>(dO + o) = make_double2(d0, d1);
+            } else {
+                if (O) { O[o] = v0; if (two) O[o + 1] = v1; }
+                if (dO) { dO[o] = d0; if (two) dO[o + 1] = d1; }
+            }
+        }
+        return;
+    }
     for (int r = 0; r < tmw; ++r) {
         const int k = row0 + rw0 + r;
         if (k >= m) break;

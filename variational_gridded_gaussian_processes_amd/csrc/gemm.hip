@@ -311,6 +311,9 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     return b->nprob++;
 }
 
+static const char* g_last_project_kernel = "";
+const char* vg_last_project_kernel() { return g_last_project_kernel; }
+
 hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
     if (b->nprob == 0 || b->total_tiles == 0) return hipSuccess;
     // a batch that cannot fill half the chip with 64 x 64 tiles and is not split-K (the m x m x m chain products) runs
@@ -332,10 +335,13 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
         return hipGetLastError();
     }
     static const bool wide = getenv("VGGP_GEMM_NARROW") == nullptr;
-    if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && b->total_tiles <= 320)
+    if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && b->total_tiles <= 320) {
+        g_last_project_kernel = "vg_gemm_gram_project_wide_kernel";
         hipLaunchKernelGGL(vg_gemm_gram_project_wide_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
-    else if (tag == VG_GEMM_TAG_GRAM_PROJECT)
+    } else if (tag == VG_GEMM_TAG_GRAM_PROJECT) {
+        g_last_project_kernel = "vg_gemm_gram_project_kernel";
         hipLaunchKernelGGL(vg_gemm_gram_project_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
+    }
     else
         hipLaunchKernelGGL(vg_gemm_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
     return hipGetLastError();

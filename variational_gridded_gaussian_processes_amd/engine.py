@@ -302,6 +302,9 @@ class Engine:
         names = [self.lib.vggp_stage_name(i).decode() for i in range(_lib.NSTAGE)]
         return dict(zip(names, list(ms))), steps.value
 
+    def project_kernel_name(self) -> str:
+        return self.lib.vggp_project_kernel_name().decode()
+
     def sumsq(self, y: torch.Tensor) -> float:
         out = C.c_double()
         check(self.lib.vggp_sumsq(self._h, _ptr(y), y.numel(), C.byref(out), _stream(self.device)))

@@ -57,3 +57,29 @@ class ShardedStep:
 
     def step(self, Y_local: torch.Tensor, yy_total: float, theta: Sequence[float]) -> Tuple[float, np.ndarray, dict]:
         return self.engine.elbo_step(Y_local, yy_total, theta)
+
+
+class ExternalCollectiveStep:
+    """The step with the collective carried by the CALLER: vggp_elbo_partials -> torch.distributed.all_reduce ->
+    vggp_elbo_finish on one explicit side stream (torch's default stream is the legacy null stream, which HIP cannot capture
+    into a graph).  bench.py falls back to it when the library's own RCCL communicator cannot be created."""
+
+    def __init__(self, engine: Engine, group: Optional["dist.ProcessGroup"] = None):
+        self.engine, self.group = engine, group
+        self.stream = torch.cuda.Stream(device=engine.device)
+        self.payload = None
+
+    def sumsq_total(self, Y_local: torch.Tensor) -> float:
+        t = torch.tensor([self.engine.sumsq(Y_local)], dtype=torch.float64, device=self.engine.device)
+        dist.all_reduce(t, group=self.group)
+        return float(t.item())
+
+    def step(self, Y_local, yy_total, theta):
+        eng = self.engine
+        if self.payload is None or self.payload.numel() != eng.payload_len:
+            self.payload = torch.empty(eng.payload_len, dtype=torch.float64, device=eng.device)
+        self.stream.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(self.stream):
+            eng.elbo_partials(Y_local, theta, self.payload)
+            dist.all_reduce(self.payload, group=self.group)
+            return eng.elbo_finish(self.payload, yy_total, theta)
