@@ -15,8 +15,9 @@ run() {   # run <name> <rocprof extra args...> -- <program args...>
     rm -rf /tmp/p_$name
     timeout -k 10 500 rocprofv3 "${extra[@]}" --kernel-trace --stats --output-format csv -d /tmp/p_$name -o $name -- python3 "$@" > $O/$name.log 2>&1
     for suf in kernel_stats kernel_trace counter_collection; do
-        f=$(find /tmp/p_$name -name "*${suf}.csv" | head -1); [ -n "$f" ] && cp $f $O/${name}_${suf}.csv
+        f=$(find /tmp/p_$name -name "*${suf}.csv" | head -1); if [ -n "$f" ]; then cp $f $O/${name}_${suf}.csv; fi
     done
+    return 0
 }
 B="$R/bench.py --steps 60 --warmup 20 --no-cpu --no-extras"
 run step -- $B                                                     &&

@@ -474,6 +474,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     vg_gemm_init(&g);
     vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
     const int st_slabs = g.p[0].ksplit;
+    vg_gemm_xcd_group(&g, 0);
     // predicted start basis of this step's eigensolvers: the previous step's tail left Qpred (Ep), 1.5 Qpred (Fp) and
     // W = Qpred Qpred^T (Wp); the Newton-Schulz step Fp += -0.5 W Qpred rides in this launch (see the tail of finish_enqueue)
     if (extrap && apply_ns)
@@ -490,21 +491,27 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
                 c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
     const int cc_slabs = g.p[0].ksplit;
-    VG_HIP(vg_gemm_launch(&g, sp));
-    if (sp == st) VG_MARK(5);
-    if (sp != st) VG_JOIN_RECORD(1);
-
-    // 6. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T
-    vg_gemm_init(&g);
+    // 6. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T: independent of the projection, so they share ITS
+    //    second launch (whose own products fill less than half the chip) unless the projection branch runs on the side stream
     int gh_slabs[2] = {1, 1};
-    for (int k = 0; k < 2; ++k) {
-        VgDim& d = c->d[k];
-        const int ig = vg_gemm_add(&g, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
-        gh_slabs[k] = g.p[ig].ksplit;
-        vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
+    auto add_gram = [&]() {
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const int ig = vg_gemm_add(&g, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
+            gh_slabs[k] = g.p[ig].ksplit;
+            vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
+        }
+    };
+    if (sp == st) add_gram();
+    VG_HIP(vg_gemm_launch(&g, sp));
+    if (sp == st) { VG_MARK(5); VG_MARK(6); }
+    if (sp != st) {
+        VG_JOIN_RECORD(1);
+        vg_gemm_init(&g);
+        add_gram();
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(6);
     }
-    VG_HIP(vg_gemm_launch(&g, st));
-    VG_MARK(6);
 
     c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs;
     // 7. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}.  Skipped inside a fused
@@ -1443,6 +1450,15 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
 extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
     if (!c || !c->out) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host8, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return VGGP_OK;
+}
+
+// diagnostic builds only (-DVG_EIG_RT): the eigensolver's global work area of dimension `dim` (which = 1: the Ritz problem's)
+extern "C" int vggp_debug_read_gwork(vggp_ctx* c, int dim, int which, void* host, int64_t offset_doubles, int64_t bytes) {
+    if (!c || !c->planned || dim < 0 || dim > 1) return VGGP_EINVAL;
+    const double* src = which ? c->d[dim].gwork2 : c->d[dim].gwork;
+    if (!src) return VGGP_EINVAL;
+    VG_HIP(hipMemcpy(host, src + offset_doubles, bytes, hipMemcpyDeviceToHost));
     return VGGP_OK;
 }
 

@@ -64,6 +64,7 @@ struct VgGemmP {
     int kchunk;        // K elements per split (multiple of VG_BK)
     double alpha;      // C = (accum ? C : 0) + alpha * A B
     int accum;
+    int xcd_group;     // 1: XCD-aware block order (vg_gemm_xcd_group): the tile rows that stream the same B block share an XCD
     int tri;           // VG_TRI_*: one operand is triangular, tiles skip the k-range where it is zero (at 128-granularity)
 };
 #define VG_TRI_NONE 0
@@ -84,6 +85,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
                 long sb_n, double* C, int ldc, int M, int N, int K, int ksplit = 1, long c_slab = 0,
                 int b_nslab = 1, long b_slab = 0, double alpha = 1.0, int accum = 0);
 #define VG_GEMM_TAG_GRAM_PROJECT 1
+void vg_gemm_xcd_group(VgGemmBatch* b, int prob);      // switch the XCD-aware block order on for a problem (if its shape allows)
 hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag = 0);
 const char* vg_last_project_kernel();      // name of the kernel the last VG_GEMM_TAG_GRAM_PROJECT launch dispatched
 

@@ -23,26 +23,28 @@ struct VgFactorArgs {
     int njobs;
 };
 
-__device__ __forceinline__ void vg_kappa(int kind, double dist, double ell, double& v, double& dv) {
-    const double r = dist / ell;
+// inv_ell = 1 / ell (a launch constant): two f64 divisions per element become multiplications (the divisions were a third of
+// the pairwise kernel's instructions: 3.8 -> TB/s at 8192^2, profiles/r2_factor_build_8192.txt)
+__device__ __forceinline__ void vg_kappa(int kind, double dist, double inv_ell, double& v, double& dv) {
+    const double r = dist * inv_ell;
     if (kind == VGGP_KIND_MATERN12) {
         const double e = exp(-r);
         v = e;
-        dv = e * r / ell;
+        dv = e * r * inv_ell;
     } else if (kind == VGGP_KIND_MATERN32) {
         const double a = 1.7320508075688772 * r;
         const double e = exp(-a);
         v = (1.0 + a) * e;
-        dv = a * a * e / ell;
+        dv = a * a * e * inv_ell;
     } else if (kind == VGGP_KIND_MATERN52) {
         const double a = 2.23606797749979 * r;
         const double e = exp(-a);
-        v = (1.0 + a + a * a / 3.0) * e;
-        dv = (a * a / 3.0) * (1.0 + a) * e / ell;
+        v = (1.0 + a + a * a * (1.0 / 3.0)) * e;
+        dv = (a * a * (1.0 / 3.0)) * (1.0 + a) * e * inv_ell;
     } else {   // RBF
         const double e = exp(-0.5 * r * r);
         v = e;
-        dv = e * r * r / ell;
+        dv = e * r * r * inv_ell;
     }
 }
 
@@ -172,7 +174,7 @@ __device__ __forceinline__ void vg_factor_elem(const VgFactorJob& J, bool kpart,
             dv = 0.0;
         }
     } else {
-        vg_kappa(J.kind, fabs(gk - x), ell, v, dv);
+        vg_kappa(J.kind, fabs(gk - x), 1.0 / ell, v, dv);
     }
 }
 

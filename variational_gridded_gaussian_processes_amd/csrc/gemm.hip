@@ -52,9 +52,24 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds) 
 
     int t = bid - p.tile_start;
     const int tiles = p.tiles_m * p.tiles_n;
-    const int ks = t / tiles;
-    t -= ks * tiles;
-    const int tm = t / p.tiles_n, tn = t - (t / p.tiles_n) * p.tiles_n;
+    int ks, tm, tn;
+    if (p.xcd_group) {
+        // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one; observed, used for speed only).  All
+        // tile rows of one (column block, k-chunk) stream the SAME block of B (the observations Y in the projection launch):
+        // they are given consecutive slots of ONE XCD, so that block crosses the fabric once and is hit in that XCD's L2 by the
+        // others; and an XCD only sees ONE k-chunk, i.e. 1 / ksplit of the A operand.  (vg_gemm_xcd_group checks the shape.)
+        const int nx = 8 / p.ksplit;                         // XCDs per k-chunk
+        const int xcd = t & 7, j = t >> 3;
+        ks = xcd / nx;
+        const int gi = j / p.tiles_m;
+        tm = j - gi * p.tiles_m;
+        tn = gi * nx + (xcd - ks * nx);
+    } else {
+        ks = t / tiles;
+        t -= ks * tiles;
+        tm = t / p.tiles_n;
+        tn = t - tm * p.tiles_n;
+    }
     const int row0 = tm * T, col0 = tn * T;
     int k_begin = ks * p.kchunk;
     int k_end = min(p.K, k_begin + p.kchunk);
@@ -304,11 +319,21 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     p.a_nslab = 1;
     p.a_slab = 0;
     p.tri = VG_TRI_NONE;
+    p.xcd_group = 0;
     p.tiles_m = (M + VG_BM - 1) / VG_BM;
     p.tiles_n = (N + VG_BN - 1) / VG_BN;
     p.tile_start = b->total_tiles;
     b->total_tiles += p.tiles_m * p.tiles_n * ksplit;
     return b->nprob++;
+}
+
+void vg_gemm_xcd_group(VgGemmBatch* b, int prob) {
+    static const bool off = getenv("VGGP_NO_XCD_GROUP") != nullptr;
+    VgGemmP& p = b->p[prob];
+    // needs: first problem of the launch (block index == slot), ksplit | 8, column blocks divisible over the XCDs of a k-chunk
+    const bool ok = !off && p.tile_start == 0 && (p.ksplit == 1 || p.ksplit == 2 || p.ksplit == 4 || p.ksplit == 8) &&
+                    (p.tiles_n % (8 / p.ksplit)) == 0;
+    p.xcd_group = ok ? 1 : 0;
 }
 
 static const char* g_last_project_kernel = "";
@@ -328,6 +353,7 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
             p.tiles_m = (p.M + 31) / 32;
             p.tiles_n = (p.N + 31) / 32;
             p.kchunk = ((p.K + 31) / 32) * 32;
+            p.xcd_group = 0;
             p.tile_start = s.total_tiles;
             s.total_tiles += p.tiles_m * p.tiles_n;
         }
@@ -335,6 +361,7 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
         return hipGetLastError();
     }
     static const bool wide = getenv("VGGP_GEMM_NARROW") == nullptr;
+    // (a 64 x 64 x 32 k-tile variant of the wide kernel -- half the barriers per MFMA -- was measured SLOWER: 28.6 vs 23.5 us)
     if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && b->total_tiles <= 320) {
         g_last_project_kernel = "vg_gemm_gram_project_wide_kernel";
         hipLaunchKernelGGL(vg_gemm_gram_project_wide_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
