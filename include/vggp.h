@@ -195,6 +195,14 @@ int vggp_qv_cov(vggp_ctx* ctx, double* cov, void* stream);
 int vggp_posterior(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t ns,
                    double* mean, double* var, void* stream);
 
+/* Dense ns x ns covariance of posterior(x*) (DEVICE [ns][ns]; ns <= 8192 and M ns <= 2^27): K** + Kuf*^T Sigma^-1 Kuf* -
+ * Kuf*^T Kuu^-1 Kuf*, kronecker_structure.py:223-229, from the step's eigenbasis (never forming Sigma); the masked variant
+ * from the dense Sigma~^-1 of the last masked step (ns <= M).  Callers that only need the diagonal use vggp_posterior. */
+int vggp_posterior_cov(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t ns, double* cov, void* stream);
+int vggp_posterior_cov_masked(vggp_ctx* ctx, const double* xs1, const double* xs2, int64_t ns, double* cov, void* stream);
+/* Dense M x M covariance of q(v) of the last masked step (Kuu Sigma^-1 Kuu on the observed subset). */
+int vggp_qv_cov_masked(vggp_ctx* ctx, double* cov, void* stream);
+
 /* building blocks (exported for tests, benchmarks and re-use) ---------------- */
 /* Unit-outputscale factor build for one dimension: A0[m][n], dA0/d ell [m][n],
  * K0[m][m], dK0/d ell [m][m] (any output pointer may be NULL).  x DEVICE [n];

@@ -63,6 +63,9 @@ SYMBOLS = {
     "vggp_posterior": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "vggp_readout": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P, _P, _I, _P]),
     "vggp_posterior_masked": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
+    "vggp_posterior_cov": (_I, [_P, _P, _P, _I64, _P, _P]),
+    "vggp_posterior_cov_masked": (_I, [_P, _P, _P, _I64, _P, _P]),
+    "vggp_qv_cov_masked": (_I, [_P, _P, _P]),
     "vggp_factor_build": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _D, _I, _P, _P, _P, _P, _P]),
     "vggp_cholesky_inverse": (_I, [_P, _P, _I64, _P, _P, C.POINTER(_D), _P]),
     "vggp_eigh": (_I, [_P, _P, _I64, _P, _P, C.POINTER(C.c_int32), _I, _P]),

@@ -25,6 +25,7 @@ extern "C" const char* vggp_last_error(void) { return g_err; }
 extern "C" int vggp_version(void) { return VGGP_VERSION; }
 
 #include "ctx.h"
+#include "factor_elem.h"
 
 static void graphs_clear(vggp_ctx* c);
 
@@ -1149,6 +1150,89 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
         VG_HIP(vg_gemm_launch(&g, st));
         VG_HIP(vg_post_combine_launch(c->theta, T1, U, Uv, nullptr, (int)m1, (int)m2, cn, mean + off, var + off, st));
     }
+    return VGGP_OK;
+}
+
+// ---- dense posterior covariance at scattered points (kronecker_structure.py:223-229) ---------------------------------------
+// T[(i1, i2)][p] = U1[i1][p] U2[i2][p]  (column-wise Khatri-Rao product), Tw = T * w[(i1, i2)]
+__global__ void vg_khatri_rao_kernel(const double* U1, const double* U2, const double* w, int m1, int m2, long ns, double* T,
+                                     double* Tw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)m1 * m2 * ns;
+    if (idx >= total) return;
+    const long u = idx / ns, p = idx - u * ns;
+    const int i1 = (int)(u / m2), i2 = (int)(u - (long)i1 * m2);
+    const double v = U1[(long)i1 * ns + p] * U2[(long)i2 * ns + p];
+    T[idx] = v;
+    if (Tw) Tw[idx] = v * w[u];
+}
+// cov[p][q] += s1 s2 kappa1(|x1_p - x1_q| / ell1) kappa2(|x2_p - x2_q| / ell2): the prior term K** of the product kernel
+__global__ void vg_prior_cov_kernel(const double* xs1, const double* xs2, long ns, int kind1, int kind2, const double* theta,
+                                    double* cov) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ns * ns) return;
+    const long p = idx / ns, q = idx - p * ns;
+    double k1, k2, d;
+    vg_kappa(kind1, fabs(xs1[p] - xs1[q]), 1.0 / theta[0], k1, d);
+    vg_kappa(kind2, fabs(xs2[p] - xs2[q]), 1.0 / theta[1], k2, d);
+    cov[idx] += theta[2] * theta[3] * k1 * k2;
+}
+hipError_t vg_prior_cov_launch(const double* xs1, const double* xs2, long ns, int kind1, int kind2, const double* theta,
+                               double* cov, hipStream_t st) {
+    hipLaunchKernelGGL(vg_prior_cov_kernel, dim3((unsigned)((ns * ns + 255) / 256)), dim3(256), 0, st, xs1, xs2, ns, kind1,
+                       kind2, theta, cov);
+    return hipGetLastError();
+}
+
+// whitened, rotated cross-covariances at x*: U_d = Q_d^T L0_d^{-1} A0_d(x*)  (m_d x ns, unit outputscale), by substitution
+static int posterior_factors(vggp_ctx* c, const double* xs1, const double* xs2, int ns, double* A1, double* A2, double* U1,
+                             double* U2, hipStream_t st, bool rotate) {
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    VgFactorJob fj[2] = {
+        VgFactorJob{xs1, d1.grid, A1, nullptr, nullptr, nullptr, ns, d1.m, d1.kind, d1.basis, 0, 0.0, c->desc.flags},
+        VgFactorJob{xs2, d2.grid, A2, nullptr, nullptr, nullptr, ns, d2.m, d2.kind, d2.basis, 1, 0.0, c->desc.flags}};
+    VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
+    VgTrsmSpec q[2] = {{d1.L0, d1.m, d1.Linv0, 16L * d1.m + 16, d1.m, A1, ns, 1, ns, d1.m, 0},
+                       {d2.L0, d2.m, d2.Linv0, 16L * d2.m + 16, d2.m, A2, ns, 1, ns, d2.m, 0}};
+    int rc = trsm_batch(q, 2, st);
+    if (rc || !rotate) return rc;
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, d1.QtPrev, d1.m, 1, A1, ns, 1, U1, ns, d1.m, ns, d1.m);
+    vg_gemm_add(&g, d2.QtPrev, d2.m, 1, A2, ns, 1, U2, ns, d2.m, ns, d2.m);
+    VG_HIP(vg_gemm_launch(&g, st));
+    return VGGP_OK;
+}
+
+extern "C" int vggp_posterior_cov(vggp_ctx* c, const double* xs1, const double* xs2, int64_t ns, double* cov, void* stream) {
+    if (!c || !c->have_step) { vg_set_error("vggp_posterior_cov: no finished ELBO step"); return VGGP_ESTATE; }
+    VG_REQUIRE(xs1 && xs2 && cov && ns >= 1, "vggp_posterior_cov: bad argument");
+    const long m1 = c->desc.m1, m2 = c->desc.m2, M = m1 * m2;
+    VG_REQUIRE(ns <= 8192 && M * ns <= (1L << 27), "vggp_posterior_cov: ns=%ld points x M=%ld is too large for a dense covariance "
+               "(use vggp_posterior for mean / variance)", (long)ns, M);
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const size_t need = (size_t)(2 * (m1 + m2) * ns + 2 * M * ns + M) * sizeof(double);
+    int rc = vg_ensure_misc(c, need);
+    if (rc) return rc;
+    double* p = (double*)c->misc;
+    double* A1 = p; p += m1 * ns;
+    double* A2 = p; p += m2 * ns;
+    double* U1 = p; p += m1 * ns;
+    double* U2 = p; p += m2 * ns;
+    double* T = p; p += M * ns;
+    double* Tw = p; p += M * ns;
+    if ((rc = posterior_factors(c, xs1, xs2, (int)ns, A1, A2, U1, U2, st, true))) return rc;
+    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, M, st));             // wq[M ..] = 1/D - 1
+    hipLaunchKernelGGL(vg_khatri_rao_kernel, dim3((unsigned)((M * ns + 255) / 256)), dim3(256), 0, st, U1, U2, c->wq + M, (int)m1,
+                       (int)m2, (long)ns, T, Tw);
+    VG_HIP(hipGetLastError());
+    // cov = s1 s2 Tw^T T  (t_p = sqrt(s1 s2) u1_p (x) u2_p for both Kuu scalings)  +  K**
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, Tw, 1, ns, T, ns, 1, cov, (int)ns, (int)ns, (int)ns, (int)M, 1, 0, 1, 0, c->h_theta[2] * c->h_theta[3], 0);
+    VG_HIP(vg_gemm_launch(&g, st));
+    VG_HIP(vg_prior_cov_launch(xs1, xs2, ns, c->d[0].kind, c->d[1].kind, c->theta, cov, st));
     return VGGP_OK;
 }
 

@@ -526,3 +526,67 @@ extern "C" int vggp_posterior_masked(vggp_ctx* c, const double* xs1, const doubl
     VG_HIP(hipStreamSynchronize(st));
     return VGGP_OK;
 }
+
+hipError_t vg_prior_cov_launch(const double* xs1, const double* xs2, long ns, int kind1, int kind2, const double* theta,
+                               double* cov, hipStream_t st);
+
+// dense covariance of posterior(x*) of the last masked step: cov = K** + s1 s2 (T^T Sigma~^{-1} T - T^T T), T = (L1^{-1} a1*) (x) (L2^{-1} a2*)
+extern "C" int vggp_posterior_cov_masked(vggp_ctx* c, const double* xs1, const double* xs2, int64_t ns, double* cov, void* stream) {
+    if (!c || !c->have_masked || !c->masked) { vg_set_error("vggp_posterior_cov_masked: no finished masked step"); return VGGP_ESTATE; }
+    VG_REQUIRE(xs1 && xs2 && cov && ns >= 1, "vggp_posterior_cov_masked: bad argument");
+    VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
+    const long m1 = w.m1, m2 = w.m2, M = w.M;
+    VG_REQUIRE(ns <= M, "vggp_posterior_cov_masked: at most M = %ld points per call (the scratch is M x M)", M);
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    int rc = vg_ensure_misc(c, (size_t)ns * 2 * (m1 + m2) * sizeof(double));
+    if (rc) return rc;
+    double* p = (double*)c->misc;
+    double* A1 = p; p += m1 * ns;
+    double* B1 = p; p += m1 * ns;
+    double* A2 = p; p += m2 * ns;
+    double* B2 = p;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const int cn = (int)ns;
+    VgFactorJob fj[2] = {
+        VgFactorJob{xs1, d1.grid, A1, nullptr, nullptr, nullptr, cn, d1.m, d1.kind, d1.basis, 0, 0.0, c->desc.flags},
+        VgFactorJob{xs2, d2.grid, A2, nullptr, nullptr, nullptr, cn, d2.m, d2.kind, d2.basis, 1, 0.0, c->desc.flags}};
+    VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, d1.Linv0, m1, 1, A1, cn, 1, B1, cn, (int)m1, cn, (int)m1);
+    vg_gemm_add(&g, d2.Linv0, m2, 1, A2, cn, 1, B2, cn, (int)m2, cn, (int)m2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    VGM_LAUNCH1D(vgm_pairprod_kernel, M * cn, st, B1, B2, (int)m1, (int)m2, (long)cn, w.R);                 // T  (M x ns)
+    if ((rc = gemm1(w.Sinv, M, 1, w.R, cn, 1, w.Sg, cn, (int)M, cn, (int)M, st))) return rc;                  // Sigma~^{-1} T
+    const double ss = c->h_theta[2] * c->h_theta[3];
+    if ((rc = gemm1(w.R, 1, cn, w.Sg, cn, 1, cov, cn, cn, cn, (int)M, st, ss, 0))) return rc;                  // + s1 s2 T^T Sigma~^{-1} T
+    if ((rc = gemm1(w.R, 1, cn, w.R, cn, 1, cov, cn, cn, cn, (int)M, st, -ss, 1))) return rc;                  // - s1 s2 T^T T
+    VG_HIP(vg_prior_cov_launch(xs1, xs2, ns, d1.kind, d2.kind, c->theta, cov, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}
+
+// dense M x M covariance of q(v) of the last masked step: S = s1^e1 s2^e2 (L1 (x) L2) Sigma~^{-1} (L1 (x) L2)^T
+__global__ void vgm_scale_e_kernel(double* x, long n, const double* theta, int e1, int e2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= (e1 > 0 ? theta[2] : 1.0 / theta[2]) * (e2 > 0 ? theta[3] : 1.0 / theta[3]);
+}
+extern "C" int vggp_qv_cov_masked(vggp_ctx* c, double* cov, void* stream) {
+    if (!c || !c->have_masked || !c->masked) { vg_set_error("vggp_qv_cov_masked: no finished masked step"); return VGGP_ESTATE; }
+    VG_REQUIRE(cov, "vggp_qv_cov_masked: null output");
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
+    const long m1 = w.m1, m2 = w.m2, M = w.M;
+    int rc;
+    const int e1 = (c->d[0].basis == VGGP_BASIS_VFF || c->d[0].basis == VGGP_BASIS_B1) ? -1 : 1;
+    const int e2 = (c->d[1].basis == VGGP_BASIS_VFF || c->d[1].basis == VGGP_BASIS_B1) ? -1 : 1;
+    VGM_LAUNCH1D(vgm_kron_kernel, M * M, st, c->d[0].L0, c->d[1].L0, (int)m1, (int)m2, w.R);
+    if ((rc = gemm1(w.R, M, 1, w.Sinv, M, 1, w.Sg, (int)M, (int)M, (int)M, (int)M, st))) return rc;
+    if ((rc = gemm1(w.Sg, M, 1, w.R, 1, M, cov, (int)M, (int)M, (int)M, (int)M, st))) return rc;
+    VGM_LAUNCH1D(vgm_scale_e_kernel, M * M, st, cov, M * M, c->theta, e1, e2);
+    VG_HIP(hipGetLastError());
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}

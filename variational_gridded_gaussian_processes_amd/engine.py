@@ -220,6 +220,24 @@ class Engine:
                                     _ptr(var), 1 if literal else 0, _stream(self.device)))
         return mean, var
 
+    def posterior_cov(self, x_star: torch.Tensor, masked: bool = False) -> torch.Tensor:
+        """Dense covariance of posterior(x*) (kronecker_structure.py:223-229), x_star [ns, 2] -> [ns, ns]."""
+        xs = x_star.to(self.device, torch.float64)
+        if xs.dim() == 1:
+            xs = torch.stack([xs, torch.zeros_like(xs)], dim=1)
+        xs1, xs2 = xs[:, 0].contiguous(), xs[:, 1].contiguous()
+        ns = xs1.shape[0]
+        cov = torch.empty(ns, ns, dtype=torch.float64, device=self.device)
+        fn = self.lib.vggp_posterior_cov_masked if masked else self.lib.vggp_posterior_cov
+        check(fn(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(cov), _stream(self.device)))
+        return cov
+
+    def qv_cov_masked(self) -> torch.Tensor:
+        M = self.m1 * self.m2
+        cov = torch.empty(M, M, dtype=torch.float64, device=self.device)
+        check(self.lib.vggp_qv_cov_masked(self._h, _ptr(cov), _stream(self.device)))
+        return cov
+
     def posterior_masked(self, x_star: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """posterior(x*) of the last masked step; x_star [ns, 2] -> mean[ns], var[ns]."""
         return self.posterior(x_star, _fn="vggp_posterior_masked")

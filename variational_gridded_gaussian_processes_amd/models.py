@@ -28,6 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import VggpError
+from .basis import B0SplineBasis, B1SplineBasis, FourierBasisMatern12
 from .engine import Engine
 
 NOISE_LOWER = 1e-4
@@ -256,22 +257,31 @@ class KroneckerStructure(torch.nn.Module):
         self._refresh()
         if self._masked:
             mean, var = self._engine.qv_masked()
-            return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
+            return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu(),
+                                      cov_fn=lambda: self._engine.qv_cov_masked().cpu())
         mean, var = self._engine.qv()
         return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu(),
                                   cov_fn=lambda: self._engine.qv_cov().cpu())
 
     def posterior(self, x_star: torch.Tensor) -> MultivariateNormal:
-        """kronecker_structure.py:199-230: mean and the diagonal of the covariance at x_star (N*, 2)."""
+        """kronecker_structure.py:199-230: mean and variance at x_star (N*, 2); `.covariance_matrix` (the reference's dense
+        N* x N* matrix, :223-229) is materialised on first access (vggp_posterior_cov: N* <= 8192, M N* <= 2^27)."""
         self._refresh()
+        xs = torch.as_tensor(x_star, dtype=torch.float64)
         post = self._engine.posterior_masked if self._masked else self._engine.posterior
-        mean, var = post(torch.as_tensor(x_star, dtype=torch.float64))
-        return MultivariateNormal(mean.cpu(), var.cpu())
+        mean, var = post(xs)
+
+        def cov():
+            self._refresh()          # the engine may have been re-planned by another model since
+            return self._engine.posterior_cov(xs, masked=self._masked).cpu()
+        return MultivariateNormal(mean.cpu(), var.cpu(), cov_fn=cov)
 
     def posterior_predictive(self, x_star: torch.Tensor) -> MultivariateNormal:
         """kronecker_structure.py:232-247: the likelihood adds the noise variance."""
         p = self.posterior(x_star)
-        return MultivariateNormal(p.mean, p.variance + self.likelihood.noise.detach().to(p.variance.dtype))
+        noise = self.likelihood.noise.detach().to(p.variance.dtype)
+        return MultivariateNormal(p.mean, p.variance + noise,
+                                  cov_fn=lambda: p.covariance_matrix + noise * torch.eye(p.mean.shape[0], dtype=p.variance.dtype))
 
     # -- dense views kept for small sizes / debugging (the hot path never forms them) ------------------------------
     def _factor(self, d: int, x: torch.Tensor):
@@ -385,6 +395,9 @@ class _B0Gridded(KroneckerStructure):
         self.delta_1 = self.mesh_1[1] - self.mesh_1[0]
         self.delta_2 = self.mesh_2[1] - self.mesh_2[0]
         self.b0_mesh_1, self.b0_mesh_2 = self.mesh_1, self.mesh_2
+        # gridded_kronecker_structure.py:1283-1284 / kronecker_structure.py:698-699 (bspline.py:81-103)
+        self.basis_1 = B0SplineBasis(self.mesh_1, self._engine)
+        self.basis_2 = B0SplineBasis(self.mesh_2, self._engine)
 
     def _basis(self):
         return "b0", self.mesh_1.double().numpy(), self.mesh_2.double().numpy()
@@ -409,6 +422,17 @@ class Matern12VFFGP(KroneckerStructure):
         # fourier.py:13, float32 like the reference (python float * int64 arange / python float)
         self.omegas_1 = (2 * torch.pi) * torch.arange(nfrequencies + 1) / (dim1lims[1] - dim1lims[0])
         self.omegas_2 = (2 * torch.pi) * torch.arange(nfrequencies + 1) / (dim2lims[1] - dim2lims[0])
+
+    @property
+    def basis_1(self) -> FourierBasisMatern12:
+        """kronecker_structure.py:464-470: the Fourier basis at the CURRENT lengthscale (the reference rebuilds it per call)."""
+        return FourierBasisMatern12(self.nfrequencies, self.dim1lims[0], self.dim1lims[1],
+                                    self.kernel_1.base_kernel.lengthscale.reshape(()).item(), self._engine)
+
+    @property
+    def basis_2(self) -> FourierBasisMatern12:
+        return FourierBasisMatern12(self.nfrequencies, self.dim2lims[0], self.dim2lims[1],
+                                    self.kernel_2.base_kernel.lengthscale.reshape(()).item(), self._engine)
 
     def _basis(self):
         g1 = np.concatenate([[self.dim1lims[0], self.dim1lims[1]], self.omegas_1.double().numpy()])
@@ -477,6 +501,8 @@ class Matern12B1SplineASVGP(KroneckerStructure):
         self.delta_1 = self.mesh_1[1] - self.mesh_1[0]
         self.delta_2 = self.mesh_2[1] - self.mesh_2[0]
         self.delta = self.delta_1
+        self.basis_1 = B1SplineBasis(self.mesh_1, self._engine)      # kronecker_structure.py:548-549
+        self.basis_2 = B1SplineBasis(self.mesh_2, self._engine)
 
     def _basis(self):
         return "b1", self.mesh_1.double().numpy(), self.mesh_2.double().numpy()
@@ -616,6 +642,7 @@ class univariate:
             self.mesh = torch.linspace(self.alim, self.blim, nknots)
             self.delta = self.mesh[1] - self.mesh[0]
             self.n_splines = nknots - 1
+            self.basis = B0SplineBasis(self.mesh, self._engine)       # univariate_structure.py:738
 
         def _basis(self):
             return "b0", self.mesh.double().numpy()
