@@ -368,7 +368,17 @@ class DenseKron:
             kc = (torch.sin(om[1:] * (me[1:] - a)[:, None]) - torch.sin(om[1:] * (me[:-1] - a)[:, None])) / om[1:]
             ks = -(torch.cos(om[1:] * (me[1:] - a)[:, None]) - torch.cos(om[1:] * (me[:-1] - a)[:, None])) / om[1:]
             return torch.cat([k0, kc, ks], dim=1)
-        raise NotImplementedError("gridded read-out: points (Matern-1/2) and vff inducing features")
+        if self.basis == "b1":
+            # GriddedMatern12ASVGP._Kvu_along_dim (gridded_kronecker_structure.py:831-838), literally: the B1 knots are the B0
+            # mesh padded by `padding` knots on either side; row i holds delta at the two knots of cell i (no hyper-parameter)
+            K = g.shape[0]
+            ns = mesh.shape[0] - 1
+            padding = (K - (ns + 1)) // 2
+            delta = (g[1] - g[0]).to(DT)
+            first = torch.zeros(K, dtype=DT)
+            first[padding] = first[padding + 1] = delta
+            return torch.vstack([torch.roll(first, i) for i in range(ns)])
+        raise NotImplementedError("gridded read-out: points (Matern-1/2), vff and b1 inducing features")
 
     def q_v_gridded(self, mesh_1: torch.Tensor, mesh_2: torch.Tensor, literal: bool = True) -> MVN:
         """:417-438 / :634-654: mean = Kvu Kuu^-1 mu_u, cov = Kvv - Kvu Kuu^-1 Kuv + Kvu X Kuv with X = S_u^-1 (literal: what

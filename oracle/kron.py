@@ -540,6 +540,13 @@ def cross_b0(f: Factor, mesh: np.ndarray, ell: float):
         kc = (np.sin(om[1:] * (mesh[1:] - a)[:, None]) - np.sin(om[1:] * (mesh[:-1] - a)[:, None])) / om[1:]
         ks = -(np.cos(om[1:] * (mesh[1:] - a)[:, None]) - np.cos(om[1:] * (mesh[:-1] - a)[:, None])) / om[1:]
         C = np.hstack([k0, kc, ks])
+    elif f.basis == "b1":
+        # GriddedMatern12ASVGP._Kvu_along_dim (gridded_kronecker_structure.py:831-838): delta at the two knots of each cell
+        ns, K = len(mesh) - 1, len(g)
+        padding = (K - (ns + 1)) // 2
+        C = np.zeros((ns, K))
+        for i in range(ns):
+            C[i, padding + i] = C[i, padding + i + 1] = g[1] - g[0]
     else:
         raise NotImplementedError(f.basis)
     kd = np.full(len(mesh) - 1, b0_K(len(mesh) - 1, float(mesh[1] - mesh[0]), ell)[0][0, 0])

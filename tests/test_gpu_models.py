@@ -329,3 +329,55 @@ def test_basis_objects_mirror_the_reference(engine):
     assert abs(fbasis.lengthscale - ell) < 1e-12
     Phi = fbasis(torch.tensor(bp["vff_a_x"])).numpy()
     assert np.abs(Phi - bp["vff_a_Phi"]).max() < 2e-7 * max(1.0, float(np.abs(bp["vff_a_omegas"]).max() * np.abs(bp["vff_a_x"] - fa).max()))
+
+
+@pytest.mark.parametrize("z_fastest", ["second", "first"])
+def test_gridded_svgp_model_vs_dense(engine, z_fastest):
+    """GriddedMatern12SVGP (gridded_kronecker_structure.py:222-460) with Z = cartesian_prod(z1, z2) in either row order:
+    q_v (the gridded read-out: mean and the reference's literal variance) and q_u against the literal dense formulas."""
+    from variational_gridded_gaussian_processes_amd.models import GriddedMatern12SVGP
+    n1, n2, ns = 24, 20, 6
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    z1, z2 = np.linspace(0.05, 0.95, 7), np.linspace(0.0, 1.0, 5)
+    if z_fastest == "second":
+        Z = torch.cartesian_prod(torch.tensor(z1), torch.tensor(z2))
+    else:
+        Z = torch.tensor(np.stack(np.meshgrid(z1, z2), axis=-1).reshape(-1, 2))          # gen_2d layout: first coordinate fastest
+    model = GriddedMatern12SVGP(torch.tensor(X), torch.tensor(y), Z, ns, (0, 1), (0.1, 0.9), engine=engine).to(torch.float64)
+    dm = D.DenseKron(X, y, "points", "matern12", torch.tensor(z1), torch.tensor(z2))
+    mesh1, mesh2 = torch.linspace(0, 1, ns + 1), torch.linspace(0.1, 0.9, ns + 1)
+    qd = dm.q_v_gridded(mesh1, mesh2, literal=True)
+    qv = model.q_v()
+    assert qv.mean.shape == (ns * ns,)
+    assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5
+    assert rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+    qc, qcd = model.q_v(literal=False), dm.q_v_gridded(mesh1, mesh2, literal=False)
+    assert rel(qc.variance.numpy(), qcd.variance.detach().numpy()) < 1e-5
+    # q_u in the row order of the caller's Z: the dense restatement orders u = i1 * m2 + i2
+    qu, qud = model.q_u(), dm.q_v()
+    ref_mean = qud.mean.detach().numpy().reshape(len(z1), len(z2))
+    got = qu.mean.numpy().reshape(len(z1), len(z2)) if z_fastest == "second" else qu.mean.numpy().reshape(len(z2), len(z1)).T
+    assert rel(got, ref_mean) < 1e-5
+    e, (ed, _) = model._elbo(), dm.elbo_and_grad()
+    assert abs(e.item() - ed.item()) <= 1e-5 * abs(ed.item())
+    with pytest.raises(ValueError):
+        GriddedMatern12SVGP(torch.tensor(X), torch.tensor(y), Z[:-1], ns, (0, 1), (0, 1), engine=engine)
+
+
+def test_gridded_asvgp_model_vs_dense(engine):
+    """GriddedMatern12ASVGP (gridded_kronecker_structure.py:685-969): B1 features on the padded mesh, the reference's own Kvu."""
+    from variational_gridded_gaussian_processes_amd.models import GriddedMatern12ASVGP
+    n1, n2, ns, pad = 24, 20, 7, 2
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    model = GriddedMatern12ASVGP(torch.tensor(X), torch.tensor(y), ns, pad, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    assert model.b0_mesh_padded_1.shape[0] == ns + 1 + 2 * pad and model.b1_basis_1.n_basis_functions == ns + 1 + 2 * pad
+    dm = D.DenseKron(X, y, "b1", "matern12", model.b0_mesh_padded_1, model.b0_mesh_padded_2)
+    qd = dm.q_v_gridded(model.b0_mesh_1, model.b0_mesh_2, literal=True)
+    qv = model.q_v()
+    assert qv.mean.shape == (ns * ns,)
+    assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5
+    assert rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+    e, (ed, _) = model._elbo(), dm.elbo_and_grad()
+    assert abs(e.item() - ed.item()) <= 1e-5 * abs(ed.item())
+    qu, qud = model.q_u(), dm.q_v()
+    assert rel(qu.mean.numpy(), qud.mean.detach().numpy()) < 1e-5

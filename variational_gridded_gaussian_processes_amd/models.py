@@ -488,6 +488,49 @@ class GriddedMatern12VFFGP(Matern12VFFGP):
         return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
 
 
+def _b0_cross_points(mesh: torch.Tensor, z: torch.Tensor, ell: float) -> torch.Tensor:
+    """Unit-outputscale Cov(v_k, f(z)) for B0 cells on `mesh` (gridded_kronecker_structure.py:281-321): (nsplines, len(z)).
+    Host-side set-up of the read-out (a few hundred numbers); cell k = (mesh[k], mesh[k+1]] like searchsorted(right=False)."""
+    me, zz = mesh.double(), z.double()
+    a, b = me[:-1, None], me[1:, None]
+    E1, E2 = ell * torch.exp(-(zz[None, :] - a).abs() / ell), ell * torch.exp(-(zz[None, :] - b).abs() / ell)
+    inside = (zz[None, :] > a) & (zz[None, :] <= b)
+    sign = torch.where(zz[None, :] <= a, 1.0, -1.0)
+    return torch.where(inside, 2 * ell - (E1 + E2), sign * (E1 - E2))
+
+
+class _GriddedReadout:
+    """q_u -> p(v | u) -> q_v on an nsplines x nsplines B0 grid through vggp_readout (mixin of the Gridded* classes)."""
+
+    def _grid_init(self, nsplines: int, griddim1lims, griddim2lims):
+        self.n_b0_splines = self.nsplines = nsplines
+        self.dim1_grid_lims, self.dim2_grid_lims = griddim1lims, griddim2lims
+        self.b0_mesh_1 = torch.linspace(griddim1lims[0], griddim1lims[1], nsplines + 1)
+        self.b0_mesh_2 = torch.linspace(griddim2lims[0], griddim2lims[1], nsplines + 1)
+        self.b0_delta_1 = self.b0_mesh_1[1] - self.b0_mesh_1[0]
+        self.b0_delta_2 = self.b0_mesh_2[1] - self.b0_mesh_2[0]
+        self.b0_basis_1 = B0SplineBasis(self.b0_mesh_1, self._engine)
+        self.b0_basis_2 = B0SplineBasis(self.b0_mesh_2, self._engine)
+
+    def _cross(self, d: int, ell: float) -> torch.Tensor:        # C_d (nsplines x m_d) at unit outputscale
+        raise NotImplementedError
+
+    def q_u(self) -> MultivariateNormal:
+        """The posterior over the inducing features (what the Kronecker base class calls q_v)."""
+        return KroneckerStructure.q_v(self)
+
+    def q_v(self, psd: bool = True, literal: bool = True) -> MultivariateNormal:
+        """mean and the diagonal of the covariance of the B0 cell features (flat index a * nsplines + b); the variance is the
+        reference's own expression (literal=True) unless literal=False asks for the conditional variance under q(u)."""
+        self._refresh()
+        l1 = self.kernel_1.base_kernel.lengthscale.reshape(()).item()
+        l2 = self.kernel_2.base_kernel.lengthscale.reshape(()).item()
+        kd1 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.b0_delta_1.double()), l1), dtype=torch.float64)
+        kd2 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.b0_delta_2.double()), l2), dtype=torch.float64)
+        mean, var = self._engine.readout(self._cross(0, l1), self._cross(1, l2), kd1, kd2, literal=literal)
+        return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
+
+
 class Matern12B1SplineASVGP(KroneckerStructure):
     """kronecker_structure.py:524-660: B1-spline (hat function) inducing features, Matern-1/2.
     Kuu_d = (A ell + B / ell + BC) / (2 s_d) (:560-614, tridiagonal), Kuf_d = hats(x) (:616-628)."""
@@ -663,3 +706,78 @@ class univariate:
 
     class Matern52SVGP(Matern12SVGP):
         kind = "matern52"
+
+
+class GriddedMatern12SVGP(_GriddedReadout, KroneckerStructure):
+    """gridded_kronecker_structure.py:222-460: inducing POINTS Z (M, 2) with a gridded read-out on B0 cells.  The reference
+    evaluates the product kernel on the rows of Z (Kuu = k(Z, Z), :252-264): that is a Kronecker product exactly when Z is the
+    cartesian product of its per-dimension coordinates, which is the case this engine covers -- Z must list
+    cartesian_prod(z1, z2) (either coordinate fastest); arbitrary scattered Z has no per-dimension factors."""
+
+    def __init__(self, X, y, Z: torch.Tensor, n_b0_splines: int, dim1_grid_lims, dim2_grid_lims, **kw):
+        KroneckerStructure.__init__(self, X, y, **kw)
+        Zt = torch.as_tensor(Z, dtype=torch.float64)
+        self.Z = torch.nn.Parameter(Zt.clone(), requires_grad=False)
+        self._z1, self._z2, self._u_of_row = _detect_cartesian(Zt)
+        self._grid_init(n_b0_splines, dim1_grid_lims, dim2_grid_lims)
+
+    def _basis(self):
+        return "points", self._z1.copy(), self._z2.copy()
+
+    def _cross(self, d: int, ell: float) -> torch.Tensor:
+        return _b0_cross_points(self.b0_mesh_1 if d == 0 else self.b0_mesh_2, torch.as_tensor(self._z1 if d == 0 else self._z2), ell)
+
+    def q_u(self) -> MultivariateNormal:
+        """:396-405, in the row order of the caller's Z."""
+        qu = KroneckerStructure.q_v(self)
+        idx = torch.as_tensor(self._u_of_row)
+        return MultivariateNormal(qu.mean[idx], qu.variance[idx])
+
+
+def _detect_cartesian(Z: torch.Tensor):
+    """Z (M, 2) listing every pair of cartesian_prod(z1, z2) exactly once, in any row order -> (z1, z2, u_of_row) with
+    u_of_row[r] = i1 * m2 + i2, the engine's inducing index of row r; raises when Z is not such a grid."""
+    Zn = Z.detach().cpu().numpy()
+    if Zn.ndim != 2 or Zn.shape[1] != 2:
+        raise ValueError("Z must be (M, 2)")
+    z1, i1 = np.unique(Zn[:, 0], return_inverse=True)
+    z2, i2 = np.unique(Zn[:, 1], return_inverse=True)
+    u = i1.astype(np.int64) * len(z2) + i2.astype(np.int64)
+    if len(z1) * len(z2) != Zn.shape[0] or len(np.unique(u)) != Zn.shape[0]:
+        raise ValueError("GriddedMatern12SVGP: Z must be a full cartesian grid cartesian_prod(z1, z2): only then is "
+                         "k(Z, Z) = kron(K1, K2) (arbitrary scattered inducing points are out of scope)")
+    return z1, z2, u
+
+
+class GriddedMatern12ASVGP(_GriddedReadout, Matern12B1SplineASVGP):
+    """gridded_kronecker_structure.py:685-969: B1-spline inducing features on the B0 mesh padded by `padding_factor` knots on
+    either side (:699-724), gridded read-out with the reference's own Cov(v, u) -- delta at the two knots of each cell
+    (:831-845; the reference's value, not the exact RKHS cross-covariance)."""
+
+    def __init__(self, X, y, n_b0_splines: int, padding_factor: int, dim1_grid_lims, dim2_grid_lims, **kw):
+        KroneckerStructure.__init__(self, X, y, **kw)
+        self._grid_init(n_b0_splines, dim1_grid_lims, dim2_grid_lims)
+        self.padding_factor = padding_factor
+
+        def padded(mesh, delta):
+            left = torch.tensor([(mesh[0] - i * delta).item() for i in range(padding_factor, 0, -1)])
+            right = torch.tensor([(mesh[-1] + i * delta).item() for i in range(1, padding_factor + 1)])
+            return torch.cat((left, mesh, right))
+        self.b0_mesh_padded_1 = padded(self.b0_mesh_1, self.b0_delta_1)
+        self.b0_mesh_padded_2 = padded(self.b0_mesh_2, self.b0_delta_2)
+        self.mesh_1, self.mesh_2 = self.b0_mesh_padded_1, self.b0_mesh_padded_2          # the B1 knots of the parent class
+        self.nknots = self.mesh_1.shape[0]
+        self.delta_1, self.delta_2 = self.mesh_1[1] - self.mesh_1[0], self.mesh_2[1] - self.mesh_2[0]
+        self.delta = self.delta_1
+        self.b1_basis_1 = self.basis_1 = B1SplineBasis(self.mesh_1, self._engine)
+        self.b1_basis_2 = self.basis_2 = B1SplineBasis(self.mesh_2, self._engine)
+
+    def _cross(self, d: int, ell: float) -> torch.Tensor:
+        mesh = self.mesh_1 if d == 0 else self.mesh_2
+        K, ns, pad = mesh.shape[0], self.nsplines, self.padding_factor
+        C = torch.zeros(ns, K, dtype=torch.float64)
+        delta = float((mesh[1] - mesh[0]).double())
+        idx = torch.arange(ns)
+        C[idx, pad + idx] = delta
+        C[idx, pad + idx + 1] = delta
+        return C
