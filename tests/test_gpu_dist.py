@@ -178,8 +178,9 @@ def test_config4_four_ranks_1024x4096_slabs_vs_structured_oracle(engine):
     rm, rv = Kr.q_v(refs[-1])
     for _, _, mean, var in res:
         assert np.abs(mean - rm).max() <= 1e-6 * np.abs(rm).max()
-        # the posterior variance is 1e-6 of the prior variance here (16.8 M observations): checked against the prior scale
-        assert np.abs(var - rv).max() <= 1e-8 * max(C4_THETA[2] * C4_THETA[3], np.abs(rv).max())
+        # (the posterior variance is 1e-6 of the prior variance here -- 16.8 M observations -- and still matches to 1e-6
+        # relative: the read-out after warm-started steps re-runs the eigensolve cold, api.hip vg_accurate_state)
+        assert np.abs(var - rv).max() <= 1e-6 * np.abs(rv).max()
 
 
 def test_rccl_transport_size_one(engine):

@@ -74,6 +74,10 @@ struct vggp_ctx {
     bool use_graph = true;
     hipGraphExec_t gexec[12] = {};
     VgGraphKey gkey[12];
+    // what the accurate (cold) recompute of the read-outs needs from the last step (api.hip vg_accurate_state)
+    bool last_warm = false, last_slabs = false, acc_valid = false;
+    const double* last_payload = nullptr;
+    double last_yy = 0.0;
     bool pred_consumed = false;       // this prediction's Newton-Schulz step has been applied to Fp (it accumulates: once only)
     bool refine_next = false;
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start
