@@ -1538,7 +1538,7 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
     const long nb1 = (n1 + 15) / 16, nb2 = (n2 + 15) / 16;
     static const bool subst_only = getenv("VGGP_KRON_SUBST") != nullptr;
     const bool small = (n1 <= VG_TRSM_BLK && n2 <= VG_TRSM_BLK) || subst_only;
-    const size_t need = (size_t)(nb1 + nb2) * 256 + (small ? 0 : (size_t)(n1 * n1 + n2 * n2 + std::max(n1 * n1, n2 * n2) + 2 * n1 * n2));
+    const size_t need = (size_t)(nb1 + nb2) * 256 + (small ? 0 : (size_t)(2 * (n1 * n1 + n2 * n2) + 4 * n1 * n2));
     int rc = vg_ensure_misc(c, need * sizeof(double));
     if (rc) return rc;
     double* D1 = (double*)c->misc;
@@ -1560,27 +1560,38 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
     // this call (BASELINE metric ii is timed from the Cholesky factors).
     double* Li1 = D2 + nb2 * 256;
     double* Li2 = Li1 + n1 * n1;
-    double* tmp = Li2 + n2 * n2;
-    double* T1 = tmp + std::max(n1 * n1, n2 * n2);
-    double* T2 = T1 + n1 * n2;
+    double* tmp1 = Li2 + n2 * n2;
+    double* tmp2 = tmp1 + n1 * n1;
+    double* T1 = tmp2 + n2 * n2;                 // two split-K slabs each
+    double* T2 = T1 + 2 * n1 * n2;
     VG_HIP(hipMemsetAsync(Li1, 0, sizeof(double) * (n1 * n1 + n2 * n2), st));
-    VgTriInvSpec sp[2] = {{L1, (long)n1, D1, Li1, tmp}, {L2, (long)n2, D2, Li2, tmp}};
-    // the two factors share `tmp` only if they run in different launches: give each its own half when both fit, else serialise
-    if ((rc = tri_inverse_batch(&sp[0], 1, st))) return rc;
-    if ((rc = tri_inverse_batch(&sp[1], 1, st))) return rc;
+    VgTriInvSpec sp[2] = {{L1, (long)n1, D1, Li1, tmp1}, {L2, (long)n2, D2, Li2, tmp2}};
+    if ((rc = tri_inverse_batch(sp, 2, st))) return rc;            // both factors ride in the same launches
+    // Four triangular-aware GEMMs.  A 1024^3 product is 256 tiles = one workgroup per CU, and the triangular skip leaves the
+    // longest tile (full K) on the critical path: it saves energy and L2 traffic, not time.  Splitting the reduction in two
+    // (slabs summed on load by the next product, two workgroups per CU) was measured SLOWER (397 vs 336 us for the whole
+    // solve: the slab-summing operand path); VGGP_KRON_KSPLIT=2 keeps it reachable.
+    const long slab = (long)n1 * n2;
+    static const char* kse = getenv("VGGP_KRON_KSPLIT");
+    const int ks = kse ? atoi(kse) : 1;
     VgGemmBatch g;
     vg_gemm_init(&g);
-    { const int i = vg_gemm_add(&g, Li1, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1); g.p[i].tri = VG_TRI_A_LOWER; }     // L1inv Y
-    VG_HIP(vg_gemm_launch(&g, st));
+    { const int i = vg_gemm_add(&g, Li1, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1, ks, slab); g.p[i].tri = VG_TRI_A_LOWER; }  // L1inv Y
+    const int s1 = g.p[0].ksplit;
+    VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
     vg_gemm_init(&g);
-    { const int i = vg_gemm_add(&g, T1, n2, 1, Li2, 1, n2, T2, (int)n2, (int)n1, (int)n2, (int)n2); g.p[i].tri = VG_TRI_B_UPPER; }    // . L2inv^T
-    VG_HIP(vg_gemm_launch(&g, st));
+    { const int i = vg_gemm_add(&g, T1, n2, 1, Li2, 1, n2, T2, (int)n2, (int)n1, (int)n2, (int)n2, ks, slab); g.p[i].tri = VG_TRI_B_UPPER;  // . L2inv^T
+      g.p[i].a_nslab = s1; g.p[i].a_slab = slab; }
+    const int s2 = g.p[0].ksplit;
+    VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
     vg_gemm_init(&g);
-    { const int i = vg_gemm_add(&g, Li1, 1, n1, T2, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1); g.p[i].tri = VG_TRI_A_UPPER; }    // L1inv^T .
-    VG_HIP(vg_gemm_launch(&g, st));
+    { const int i = vg_gemm_add(&g, Li1, 1, n1, T2, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1, ks, slab, s2, slab); g.p[i].tri = VG_TRI_A_UPPER; }  // L1inv^T .
+    const int s3 = g.p[0].ksplit;
+    VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
     vg_gemm_init(&g);
-    { const int i = vg_gemm_add(&g, T1, n2, 1, Li2, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2); g.p[i].tri = VG_TRI_B_LOWER; }     // . L2inv
-    VG_HIP(vg_gemm_launch(&g, st));
+    { const int i = vg_gemm_add(&g, T1, n2, 1, Li2, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2); g.p[i].tri = VG_TRI_B_LOWER;            // . L2inv
+      g.p[i].a_nslab = s3; g.p[i].a_slab = slab; }
+    VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
     return VGGP_OK;
 }
 

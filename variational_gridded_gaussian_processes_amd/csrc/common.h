@@ -85,6 +85,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
                 long sb_n, double* C, int ldc, int M, int N, int K, int ksplit = 1, long c_slab = 0,
                 int b_nslab = 1, long b_slab = 0, double alpha = 1.0, int accum = 0);
 #define VG_GEMM_TAG_GRAM_PROJECT 1
+#define VG_GEMM_TAG_WIDE 2          // about one workgroup per CU and a long reduction: the 8-wave tile
 void vg_gemm_xcd_group(VgGemmBatch* b, int prob);      // switch the XCD-aware block order on for a problem (if its shape allows)
 hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag = 0);
 const char* vg_last_project_kernel();      // name of the kernel the last VG_GEMM_TAG_GRAM_PROJECT launch dispatched

@@ -286,6 +286,10 @@ __global__ __launch_bounds__(512) void vg_gemm_gram_project_wide_kernel(const Vg
     __shared__ double lds[2 * VgTile<64, 16>::TILE];
     vg_gemm_body<64, 16, 512>(b, lds);
 }
+__global__ __launch_bounds__(512) void vg_gemm_wide_kernel(const VgGemmBatch b) {      // the same 8-wave tile for other launches
+    __shared__ double lds[2 * VgTile<64, 16>::TILE];
+    vg_gemm_body<64, 16, 512>(b, lds);
+}
 __global__ __launch_bounds__(256) void vg_gemm_small_kernel(const VgGemmBatch b) {
     __shared__ double lds[2 * VgTile<32, 32>::TILE];
     vg_gemm_body<32, 32>(b, lds);
@@ -369,6 +373,8 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
         g_last_project_kernel = "vg_gemm_gram_project_kernel";
         hipLaunchKernelGGL(vg_gemm_gram_project_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
     }
+    else if (tag == VG_GEMM_TAG_WIDE && wide && b->total_tiles <= 320)
+        hipLaunchKernelGGL(vg_gemm_wide_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
     else
         hipLaunchKernelGGL(vg_gemm_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
     return hipGetLastError();
