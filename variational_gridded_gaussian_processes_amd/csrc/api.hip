@@ -405,6 +405,12 @@ static int trsm_inplace(const double* L, long m, long ldl, const double* Dinv, d
 
 // Enqueue-only halves of the step (no host synchronisation, no host-side reads): they run either directly on the
 // caller's stream (profiling mode) or once under stream capture, after which the step is a single graph launch.
+// riders: see vg_partials_enqueue.  Off in profiling mode (every stage is then its own launch and can be timed) and with VGGP_NO_RIDE=1.
+static bool vg_ride(const vggp_ctx* c) {
+    static const bool off = getenv("VGGP_NO_RIDE") != nullptr;
+    return !off && !c->prof && c->desc.m1 <= 128 && c->desc.m2 <= 128;
+}
+
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap, bool fused, bool apply_ns) {
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
@@ -472,47 +478,66 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     //    S = [B2;V2] Y (split-K slabs): the only pass over Y; then [C;C1] = [B1;V1] S_B, C2 = B1 S_V (S slabs summed on
     //    load; split-K over n1).
     hipStream_t sp = (fused && !extrap) ? sx : st;
+    // "Riders" (fused warm step): the two projection launches are not enqueued here at all -- their batches are handed to
+    // finish_enqueue, which attaches them to the single-workgroup launches of the eigensolver chain (row QR / Ritz solve /
+    // main solve) as extra workgroups, so they run BESIDE that chain on the 250 idle CUs instead of in front of it.
+    const bool ride = fused && !reduce && sp == st && vg_ride(c);
     if (sp != st) VG_FORK(1);
-    vg_gemm_init(&g);
-    vg_gemm_add(&g, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
-    const int st_slabs = g.p[0].ksplit;
-    vg_gemm_xcd_group(&g, 0);
+    VgGemmBatch gp, gc;
+    vg_gemm_init(&gp);
+    vg_gemm_add(&gp, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
+    const int st_slabs = gp.p[0].ksplit;
+    vg_gemm_xcd_group(&gp, 0);
     // predicted start basis of this step's eigensolvers: the previous step's tail left Qpred (Ep), 1.5 Qpred (Fp) and
     // W = Qpred Qpred^T (Wp); the Newton-Schulz step Fp += -0.5 W Qpred rides in this launch (see the tail of finish_enqueue)
-    if (extrap && apply_ns)
-        for (int k = 0; k < 2; ++k) {
-            VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
-        }
-    VG_HIP(vg_gemm_launch(&g, sp, VG_GEMM_TAG_GRAM_PROJECT));
-    if (sp == st) VG_MARK(4);
-    vg_gemm_init(&g);
+    // -- or in the Gram launch when the projection itself is deferred
+    auto add_ns = [&](VgGemmBatch* b) {
+        if (extrap && apply_ns)
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                vg_gemm_add(b, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
+            }
+    };
+    if (!ride) {
+        add_ns(&gp);
+        VG_HIP(vg_gemm_launch(&gp, sp, VG_GEMM_TAG_GRAM_PROJECT));
+        if (sp == st) VG_MARK(4);
+    }
+    vg_gemm_init(&gc);
     const long cc_slab = 3L * m1 * m2;
-    vg_gemm_add(&g, d1.BV, n1, 1, c->St, 1, n1, c->CCslab, (int)m2, (int)(2 * m1), (int)m2, (int)n1, c->cc_split, cc_slab,
+    vg_gemm_add(&gc, d1.BV, n1, 1, c->St, 1, n1, c->CCslab, (int)m2, (int)(2 * m1), (int)m2, (int)n1, c->cc_split, cc_slab,
                 st_slabs, 2L * m2 * n1);
-    vg_gemm_add(&g, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
+    vg_gemm_add(&gc, d1.BV, n1, 1, c->St + m2 * n1, 1, n1, c->CCslab + 2 * m1 * m2, (int)m2, (int)m1, (int)m2, (int)n1,
                 c->cc_split, cc_slab, st_slabs, 2L * m2 * n1);
-    const int cc_slabs = g.p[0].ksplit;
+    const int cc_slabs = gc.p[0].ksplit;
     // 6. Gram pairs [G0;H0] = [B;V] B^T (split-K slabs), Mk = X Linv0^T: independent of the projection, so they share ITS
     //    second launch (whose own products fill less than half the chip) unless the projection branch runs on the side stream
     int gh_slabs[2] = {1, 1};
-    auto add_gram = [&]() {
+    auto add_gram = [&](VgGemmBatch* b) {
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            const int ig = vg_gemm_add(&g, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
-            gh_slabs[k] = g.p[ig].ksplit;
-            vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
+            const int ig = vg_gemm_add(b, d.BV, d.n, 1, d.BV, 1, d.n, d.GHslab, d.m, 2 * d.m, d.m, d.n, d.gh_split, 2L * d.m * d.m);
+            gh_slabs[k] = b->p[ig].ksplit;
+            vg_gemm_add(b, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
         }
     };
-    if (sp == st) add_gram();
-    VG_HIP(vg_gemm_launch(&g, sp));
-    if (sp == st) { VG_MARK(5); VG_MARK(6); }
-    if (sp != st) {
-        VG_JOIN_RECORD(1);
+    if (ride) {
         vg_gemm_init(&g);
-        add_gram();
+        add_gram(&g);
+        add_ns(&g);
         VG_HIP(vg_gemm_launch(&g, st));
-        VG_MARK(6);
+        c->ride_proj = gp; c->ride_cc = gc; c->ride_pending = true;
+    } else {
+        if (sp == st) add_gram(&gc);
+        VG_HIP(vg_gemm_launch(&gc, sp));
+        if (sp == st) { VG_MARK(5); VG_MARK(6); }
+        if (sp != st) {
+            VG_JOIN_RECORD(1);
+            vg_gemm_init(&g);
+            add_gram(&g);
+            VG_HIP(vg_gemm_launch(&g, st));
+            VG_MARK(6);
+        }
     }
 
     c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs;
@@ -551,6 +576,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     const int ccn = from_slabs ? c->cc_slabs : 1;
     const long ccs = 3L * m1 * m2;
     VgGemmBatch g;
+    const bool ride = from_slabs && c->ride_pending;      // the projection launches were deferred to this chain (vg_partials_enqueue)
+    int ride_stage = 0;                                   // 0: S pending, 1: [C;C1;C2] pending, 2: done
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     hipStream_t sx = vg_side(c, st);
@@ -590,7 +617,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             const long r = d.sub_r;
             qj[k] = VgRowQrJob{d.Zs, d.V1s, d.sub_r, d.m, d.Fp + r * d.m, d.E + r * d.m, (long)(d.m - r) * d.m};   // + E[r:] <- S[r:]
         }
-        VG_HIP(vg_rowqr_launch(qj, 2, st));
+        VG_HIP(vg_rowqr_launch(qj, 2, st, ride ? &c->ride_proj : nullptr));      // + rider: S = [B2;V2] Y
+        if (ride) ride_stage = 1;
         VG_MARK(9);
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
@@ -617,7 +645,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             sj[k].perm = d.perm2;
             sj[k].err = d.status + 1;
         }
-        VG_HIP(vg_eigh_launch(sj, 2, st));                                                                           // Ritz pairs
+        VG_HIP(vg_eigh_launch(sj, 2, st, ride ? &c->ride_cc : nullptr));                              // Ritz pairs (+ rider: [C;C1;C2])
+        if (ride) ride_stage = 2;
         VG_MARK(11);
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
@@ -713,8 +742,12 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         ej[k].polish0 = (warm && refine) ? 1 : 0;
         ej[k].sparse_first = (warm && subspace) ? 1 : 0;
     }
-    VG_HIP(vg_eigh_launch(ej, 2, st));      // counters were zeroed by the clear kernel at the start of the step
+    // (counters were zeroed by the clear kernel at the start of the step)
+    VG_HIP(vg_eigh_launch(ej, 2, st, (ride && ride_stage == 0) ? &c->ride_proj : nullptr));
     VG_MARK(13);
+    if (ride && ride_stage == 0) ride_stage = 1;
+    if (ride && ride_stage == 1) VG_HIP(vg_gemm_launch(&c->ride_cc, st));      // no second host launch in this chain: by itself
+    c->ride_pending = false;
     if (from_slabs) VG_JOIN_WAIT(1);          // fused step: the projection branch (S, C slabs) ran beside the eigensolver chain
 
     // 8. rotate into the eigenbasis: first the right factors ...

@@ -182,14 +182,16 @@ struct VgEigJob {
 // Row orthonormalisation for the subspace start (eigh.hip): V1 = rows of Z (r x m, r <= 64, m <= 128) orthonormalised in the
 // given order (classical Gram-Schmidt, re-orthogonalised), one workgroup per job; also copies cp_src -> cp_dst (cp_n doubles).
 struct VgRowQrJob { const double* Z; double* V1; int r; int m; const double* cp_src; double* cp_dst; long cp_n; };
-hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st);
+// `rider` (both launchers): a GEMM batch executed by extra workgroups of the same launch, beside the single-workgroup jobs
+struct VgGemmBatch;
+hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);
 hipError_t vg_identity_launch(double* A, int m, hipStream_t st);
 // First-order refinement of a warm start (eigh.hip): from Gw = S G S^T, E_ij = g_ij / (g_ii - g_jj) for the elements above
 // the eigensolver's threshold; outputs E and R1 = I + E (both [m][m]); E = 0, R1 = I when some |E_ij| > 1e-3.
 struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol; };
 hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st);
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
-hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid = nullptr);
+hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);
 hipError_t vg_eigh_setup();
 
 // ---- m-space elementwise / reductions (mspace.hip) -----------------------------

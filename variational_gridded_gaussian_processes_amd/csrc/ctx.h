@@ -78,6 +78,8 @@ struct vggp_ctx {
     bool last_warm = false, last_slabs = false, acc_valid = false;
     const double* last_payload = nullptr;
     double last_yy = 0.0;
+    VgGemmBatch ride_proj, ride_cc;   // the projection launches of a fused warm step, deferred to the eigensolver chain as riders
+    bool ride_pending = false;
     bool pred_consumed = false;       // this prediction's Newton-Schulz step has been applied to Fp (it accumulates: once only)
     bool refine_next = false;
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start

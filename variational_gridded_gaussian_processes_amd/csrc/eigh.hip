@@ -12,7 +12,7 @@
 //   being applied to the eigenvector matrix here (that would not fit LDS next to G).
 // Kernel 2 (vg_replay_kernel, m/16 workgroups per matrix): replays the rotation log on a block
 //   of columns of Q^T; every wave owns its columns outright, so there is no barrier per round.
-#include "common.h"
+#include "gemm_body.h"
 
 #include <cstdlib>
 
@@ -37,6 +37,8 @@ struct VgEigArgs {
     int use_lds[2];
     int fast[2];       // dense sweeps with fixed addresses (two copies of G fit LDS)
     int rp_cols;       // replay columns per workgroup (4 per working wave)
+    int nx;            // workgroups per job: 1 producer + nx - 1 replay
+    int neig;          // njobs * nx; linear block ids >= neig are tiles of the rider
 };
 
 // circle-method pairing of m2 (even) players in round r: pair index k -> (p, q)
@@ -156,7 +158,7 @@ __device__ __forceinline__ VgAngle vg_angle3(double gpp, double gqq, double gpq,
 // One scan of the strict lower triangle (identity layout, diagonal in Dc): E_ij = g_ij / (g_ii - g_jj) for the elements
 // above thr, stored speculatively (strict lower triangle, row-major, write-through) in J.gwork; returns whether the polish
 // R = I + E + E^2/2 may replace the remaining sweeps (see vg_jacobi_fast).  rs: 48 doubles of LDS scratch.
-__device__ bool vg_polish_scan(const VgEigJob& J, const double* Wc, const double* Dc, double thr, double* rs) {
+__device__ __forceinline__ bool vg_polish_scan(const VgEigJob& J, const double* Wc, const double* Dc, double thr, double* rs) {
     const int m = J.m, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     double sE = 0.0, sG = 0.0, mE = 0.0;
     double* E = J.gwork;
@@ -188,7 +190,7 @@ __device__ bool vg_polish_scan(const VgEigJob& J, const double* Wc, const double
 
 // returns the buffer that holds G (packed, identity layout, diagonal included) when the phase ends; converged is set
 // when a whole sweep rotated nothing.  Wa must already hold the packed lower triangle.
-__device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, double2* cs, double* Dd, int* nact_s, double thr,
+__device__ __forceinline__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, double2* cs, double* Dd, int* nact_s, double thr,
                                   int& nlog, int& sweeps, int& status, bool& converged, bool& polished) {
     const int m = J.m, m2 = m + (m & 1), half = m2 >> 1, n1 = m2 - 1;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -406,7 +408,7 @@ __device__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa, double* Wb, dou
 #endif
 
 template <bool INLDS>
-__device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, VgActRec* actrec, unsigned char* isact,
+__device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPairRec* pq, VgActRec* actrec, unsigned char* isact,
                                int* nact_s, double* red, bool fast) {
     const int m = J.m;
     const int m2 = m + (m & 1), half = m2 >> 1;
@@ -658,7 +660,7 @@ __device__ void vg_jacobi_body(const VgEigJob& J, double* W, double2* cs, VgPair
 // ---- replay role: a block of VG_RP_COLS columns of Q^T per workgroup, fed by the producer's log ----------
 #define VG_RP_CHUNK_BYTES 16384
 
-__device__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, double* dyn, int* s_sync) {
+__device__ __forceinline__ void vg_replay_body(const VgEigJob& J, int cblock, int VG_RP_COLS, double* dyn, int* s_sync) {
     const int m = J.m, m2 = m + (m & 1), half = m2 >> 1;
     const int VG_RP_LD = VG_RP_COLS + 1, csh = VG_RP_COLS == 64 ? 6 : (VG_RP_COLS == 32 ? 5 : 4);
     const int j0 = cblock * VG_RP_COLS;
@@ -880,7 +882,7 @@ __device__ __forceinline__ double2 vg_angle(double spp, double sqq, double spq, 
     return make_double2(c, tt * c);
 }
 
-__device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgPairRec* pq, int* flags, double* red) {
+__device__ __forceinline__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgPairRec* pq, int* flags, double* red) {
     const int m = J.m;
     const int nb = 2 * ((m + 31) / 32), Mp = 16 * nb, npair = nb >> 1;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -1202,7 +1204,7 @@ __device__ void vg_bjacobi_body(const VgEigJob& J, double* dyn, double2* cs, VgP
 }
 
 // replay role for the block log: a 16-column tile of Q^T per workgroup; wave g applies pair g's U with MFMA
-__device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int* s_sync) {
+__device__ __forceinline__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int* s_sync) {
     const int m = J.m;
     const int nb = 2 * ((m + 31) / 32), Mp = 16 * nb, npair = nb >> 1;
     const int j0 = cblock * 16;
@@ -1278,12 +1280,14 @@ __device__ void vg_breplay_body(const VgEigJob& J, int cblock, double* dyn, int*
     }
 }
 
-// One launch, two roles: blockIdx.x == 0 is the Jacobi producer of matrix blockIdx.y, blockIdx.x >= 1 replay its
-// rotation log on column block blockIdx.x-1 of Q^T while the producer is still running (the replay is ~3x faster
+// One launch, up to three roles.  Linear block id = job * nx + bx: bx == 0 is the Jacobi producer of the job's matrix, bx >= 1 replay its
+// rotation log on column block bx-1 of Q^T while the producer is still running (the replay is ~3x faster
 // per round, so it finishes a few microseconds after the producer).  At most 2*(1+16) workgroups of up to 1024 threads / 136 KB LDS:
 // co-resident on an otherwise idle MI355X, NOT guaranteed on a shared GPU -- hence the bounded spin of the replay
 // workgroups and the error word (VgEigJob::err) they raise on a timeout (surfaces as VGGP_ENOCONV).
-__global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
+// `rider`: optional GEMM batch executed by extra workgroups of this launch (a parameter of its own: inside VgEigArgs the
+// compiler copies the whole argument block to scratch memory at the start of every workgroup)
+__global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a, const VgGemmBatch rider) {
     extern __shared__ __attribute__((aligned(16))) double vg_eig_dyn[];   // double2 views of it are read with ds_read_b128
     __shared__ double2 cs[512];
     __shared__ VgPairRec pq[512];
@@ -1291,15 +1295,22 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a) {
     __shared__ unsigned char isact[512];
     __shared__ int nact_s[2];
     __shared__ double red[16];
-    const VgEigJob& J = a.job[blockIdx.y];
+    const int bid = blockIdx.x;
+    if (bid >= a.neig) {          // rider role: one 64 x 64 tile of the attached GEMM batch, 8 waves (the other 8 leave)
+        if (threadIdx.x >= 512) return;
+        vg_gemm_body<64, 16, 512>(rider, vg_eig_dyn, bid - a.neig);
+        return;
+    }
+    const int by = bid >= a.nx ? 1 : 0, bx = bid - by * a.nx;      // at most two jobs (no division: keeps the index scalar)
+    const VgEigJob& J = a.job[by];
     const bool block_mode = J.block && J.m <= VG_BJ_MAX_M;
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         if (block_mode) vg_bjacobi_body(J, vg_eig_dyn, cs, pq, nact_s, red);
-        else if (a.use_lds[blockIdx.y]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, actrec, isact, nact_s, red, a.fast[blockIdx.y] != 0);
+        else if (a.use_lds[by]) vg_jacobi_body<true>(J, vg_eig_dyn, cs, pq, actrec, isact, nact_s, red, a.fast[by] != 0);
         else vg_jacobi_body<false>(J, J.gwork, cs, pq, actrec, isact, nact_s, red, false);
     } else {
-        if (block_mode) vg_breplay_body(J, blockIdx.x - 1, vg_eig_dyn, nact_s);
-        else vg_replay_body(J, blockIdx.x - 1, a.rp_cols, vg_eig_dyn, nact_s);
+        if (block_mode) vg_breplay_body(J, bx - 1, vg_eig_dyn, nact_s);
+        else vg_replay_body(J, bx - 1, a.rp_cols, vg_eig_dyn, nact_s);
     }
 }
 
@@ -1319,9 +1330,14 @@ size_t vg_eigh_log_bytes(int m) {
 // with phi ~ 1e-3), so their Gram matrix is numerically singular and Cholesky-QR is out; the deflation has to run top-down.
 // Classical Gram-Schmidt with re-orthogonalisation, row by row, everything in LDS: the k dot products of a row are taken
 // by the 16 waves in parallel, then 128 lanes subtract; a third pass when a pass removed most of the row.
-struct VgRowQrArgs { VgRowQrJob job[2]; };
-__global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
+struct VgRowQrArgs { VgRowQrJob job[2]; int njobs; };
+__global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, const VgGemmBatch rider) {
     extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
+    if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
+        if (threadIdx.x >= 512) return;
+        vg_gemm_body<64, 16, 512>(rider, vq_dyn, blockIdx.x - a.njobs);
+        return;
+    }
     const VgRowQrJob& J = a.job[blockIdx.x];
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* V = vq_dyn;                 // [r][m]: rows < k are finished, row k is in work, rows > k still hold Z (one load)
@@ -1410,17 +1426,23 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a) {
     for (long i = tid + 16 * 1024L; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];      // (m <= 128: never taken)
 }
 
-hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st) {
+static const size_t VG_RIDER_LDS = 2 * VgTile<64, 16>::TILE * sizeof(double);
+
+hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider) {
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     VgRowQrArgs a;
+    a.njobs = njobs;
+    VgGemmBatch rb;
+    rb.nprob = 0; rb.total_tiles = 0;
     size_t lds = 0;
+    if (rider && rider->nprob > 0 && rider->total_tiles > 0) { rb = *rider; lds = VG_RIDER_LDS; }
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         if (jobs[j].r < 1 || jobs[j].r > 64 || jobs[j].m < jobs[j].r || jobs[j].m > 128) return hipErrorInvalidValue;
         const size_t need = (size_t)jobs[j].r * jobs[j].m * sizeof(double);
         if (need > lds) lds = need;
     }
-    hipLaunchKernelGGL(vg_rowqr_kernel, dim3(njobs), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL(vg_rowqr_kernel, dim3(njobs + rb.total_tiles), dim3(1024), lds, st, a, rb);
     return hipGetLastError();
 }
 
@@ -1494,11 +1516,13 @@ hipError_t vg_eigh_setup() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
 }
 
-hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEvent_t mid) {
-    (void)mid;
+hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider) {
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     VgEigArgs a;
     a.njobs = njobs;
+    VgGemmBatch rb;
+    rb.nprob = 0; rb.total_tiles = 0;
+    if (rider && rider->nprob > 0 && rider->total_tiles > 0) rb = *rider;
     static const char* fs_env = getenv("VGGP_EIG_FAST_SWITCH");      // tuning / A-B switch (0 disables the dense phase)
     static const char* tol_env = getenv("VGGP_EIG_TOL");
     static const bool no_polish = getenv("VGGP_EIG_NO_POLISH") != nullptr;
@@ -1535,6 +1559,9 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, hipEv
     }
     if (lds > 136 * 1024) return hipErrorInvalidValue;
     const int ncb = (maxm2 + VG_RP_COLS - 1) / VG_RP_COLS;
-    hipLaunchKernelGGL(vg_eigh_kernel, dim3(1 + ncb, njobs), dim3(1024), lds, st, a);
+    a.nx = 1 + ncb;
+    a.neig = njobs * a.nx;
+    if (rb.total_tiles > 0 && lds < VG_RIDER_LDS) lds = VG_RIDER_LDS;
+    hipLaunchKernelGGL(vg_eigh_kernel, dim3(a.neig + rb.total_tiles), dim3(1024), lds, st, a, rb);
     return hipGetLastError();
 }
