@@ -1638,7 +1638,8 @@ extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
 // diagnostic builds only (-DVG_EIG_RT): the eigensolver's global work area of dimension `dim` (which = 1: the Ritz problem's)
 extern "C" int vggp_debug_read_gwork(vggp_ctx* c, int dim, int which, void* host, int64_t offset_doubles, int64_t bytes) {
     if (!c || !c->planned || dim < 0 || dim > 1) return VGGP_EINVAL;
-    const double* src = which ? c->d[dim].gwork2 : c->d[dim].gwork;
+    // which = 2: Gw (the matrix the main eigensolver started from), 3: the Ritz matrix Hs, 4: lam0
+    const double* src = which == 2 ? c->d[dim].Gw : which == 3 ? c->d[dim].Hs : which == 4 ? c->d[dim].lam0 : which ? c->d[dim].gwork2 : c->d[dim].gwork;
     if (!src) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host, src + offset_doubles, bytes, hipMemcpyDeviceToHost));
     return VGGP_OK;

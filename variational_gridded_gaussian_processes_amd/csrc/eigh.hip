@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #define VG_EIG_TOL 1e-13         // default relative off-diagonal threshold (VgEigJob::tol)
+#define VG_EIG_TOL_SUB 1e-12     // ... of a sparse_first job (see vg_jacobi_body)
 #ifndef VG_BJ_MAX_M
 #define VG_BJ_MAX_M 128            // block Jacobi up to this size, scalar cyclic Jacobi beyond
 #endif
@@ -453,7 +454,11 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
     __syncthreads();
     double fro = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
-    const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
+    // sparse_first (subspace start): G arrives as E G E^T through two GEMMs, i.e. with rounding noise of ~sqrt(m) eps ||G||
+    // in every element (measured at 1024^2 RBF, m = 128: 20 elements of the range block at 1-5x the default threshold, nothing
+    // else above it; tools/dbg_gw.py) -- the default threshold sits below that floor and the solver then spends 15-20 rounds
+    // (40 us) rotating noise.  VG_EIG_TOL_SUB = 64 eps m puts the threshold above it.
+    const double thr = (J.tol > 0.0 ? J.tol : (J.sparse_first ? VG_EIG_TOL_SUB : VG_EIG_TOL)) * sqrt(fro) / (double)m;
     int nlog = 0, sweeps = 0, status = 0;
     bool converged = false, polished = false;
     RT(1);
