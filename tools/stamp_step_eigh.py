@@ -29,3 +29,8 @@ for which, name in ((1, "ritz (r x r)"), (0, "main")):
         rc = e.lib.vggp_debug_read_gwork(e._h, dim, which, buf, mm * mm + 8, 64)
         t = np.array(list(buf)).astype(float) * 10.0 / 1e3
         print(f"{name} dim {dim}: rc {rc}  load+norm {t[1]-t[0]:.1f}  dense {t[2]-t[1]:.1f}  sparse {t[3]-t[2]:.1f}  sort+lam+DONE {t[4]-t[3]:.1f} | producer {t[4]-t[0]:.1f}  replay-0 done at {t[5]-t[0]:.1f} us")
+
+for dim in (0, 1):
+    cnt = (C.c_int32 * 4)()
+    e.lib.vggp_debug_read_gwork(e._h, dim, 5, cnt, 0, 16)
+    print(f"ritz dim {dim}: logged rounds {cnt[0]}, sweeps {cnt[1] & 0xff}, rank {cnt[1] >> 8}, status {cnt[2]}")

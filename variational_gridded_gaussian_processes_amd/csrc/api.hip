@@ -644,6 +644,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
                              (long)vg_eigh_log_bytes(d.m), 0};
             sj[k].perm = d.perm2;
             sj[k].err = d.status + 1;
+            sj[k].newton = 1;
         }
         VG_HIP(vg_eigh_launch(sj, 2, st, ride ? &c->ride_cc : nullptr));                              // Ritz pairs (+ rider: [C;C1;C2])
         if (ride) ride_stage = 2;
@@ -1638,8 +1639,8 @@ extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
 // diagnostic builds only (-DVG_EIG_RT): the eigensolver's global work area of dimension `dim` (which = 1: the Ritz problem's)
 extern "C" int vggp_debug_read_gwork(vggp_ctx* c, int dim, int which, void* host, int64_t offset_doubles, int64_t bytes) {
     if (!c || !c->planned || dim < 0 || dim > 1) return VGGP_EINVAL;
-    // which = 2: Gw (the matrix the main eigensolver started from), 3: the Ritz matrix Hs, 4: lam0
-    const double* src = which == 2 ? c->d[dim].Gw : which == 3 ? c->d[dim].Hs : which == 4 ? c->d[dim].lam0 : which ? c->d[dim].gwork2 : c->d[dim].gwork;
+    // which = 2: Gw (the matrix the main eigensolver started from), 3: the Ritz matrix Hs, 4: lam0, 5: the Ritz solve's counters (ints)
+    const double* src = which == 5 ? reinterpret_cast<const double*>(c->d[dim].counters2) : which == 2 ? c->d[dim].Gw : which == 3 ? c->d[dim].Hs : which == 4 ? c->d[dim].lam0 : which ? c->d[dim].gwork2 : c->d[dim].gwork;
     if (!src) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host, src + offset_doubles, bytes, hipMemcpyDeviceToHost));
     return VGGP_OK;

@@ -176,6 +176,7 @@ struct VgEigJob {
     int polish = 1;        // dense phase: replace the remaining sweeps by a first-order polish when its a-priori bound allows
     int* err = nullptr;    // optional device word the replay workgroups OR a 1 into when they give up waiting for the producer
     int polish0 = 0;       // also try the polish before the first sweep (the start basis was refined by vg_refine_launch)
+    int newton = 0;        // nearly diagonal small problem (m <= 48, no start basis): try the Newton start first (vg_newton_diag)
     int sparse_first = 0;  // skip the dense phase: the start basis already block-diagonalises G (subspace start), a few elements remain
 };
 #define VG_EIG_RANK_CUT 1e-14   // eigenvalues above this fraction of the largest count towards the numerical rank (counters[1] >> 8)

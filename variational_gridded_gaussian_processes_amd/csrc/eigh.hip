@@ -23,6 +23,8 @@
 #endif
 #define VG_EIG_DONE (1 << 30)   // progress word: rounds published | DONE
 #define VG_EIG_POLISH (1 << 28) // ... | POLISH: after the logged rotations, Q^T <- (I + E + E^2/2) Q^T with E in gwork
+#define VG_EIG_DIRECT (1 << 27) // ... | DIRECT: the producer wrote Q^T itself (Newton start, see vg_newton_diag): nothing to replay or store
+#define VG_EIG_NEWTON_MAX_M 48   // largest problem the Newton start takes (five m x m LDS buffers behind the two packed copies of G)
 #define VG_POLISH_EMAX 1e-3     // largest first-order rotation the polish accepts
 typedef double vg_bd4 __attribute__((ext_vector_type(4)));
 #define VG_EIG_LAG 9             // rounds whose log stores may still be in flight: vmcnt(16) with >= 2 VMEM ops per storing wave per round, +1
@@ -402,6 +404,130 @@ __device__ __forceinline__ double* vg_jacobi_fast(const VgEigJob& J, double* Wa,
     return Wfin;
 }
 
+
+// ---- Newton start for small, nearly diagonal problems (the Ritz matrix of the subspace start) -------------------------------
+// H0 = V1 G V1^T of a warm step is diagonal up to first order in the hyper-parameter change (tools/studies/
+// ritz_sweeps_study.py: max |h_ij / (h_jj - h_ii)| = 7e-3 at a 1 % change of the lengthscale, r = 24), so the diagonalising
+// rotation is found by a Newton iteration instead of Jacobi sweeps:  E_ij = h_ij / (h_jj - h_ii) for the elements above the
+// threshold (skew), R = I + E + E^2 / 2, W <- W R re-orthonormalised by one Newton-Schulz step, H <- W^T H0 W from the ORIGINAL
+// matrix (so neither the O(E^3) departure of R from orthogonality nor rounding accumulates).  Quadratic: 7e-3 -> 1e-5 -> 2e-10
+// -> below the threshold, i.e. three iterations of six r x r x r products on the matrix cores against 46 Jacobi rounds
+// of 0.63 us plus the hand-off to the replay workgroups.  A start that is not nearly diagonal (some |E_ij| >= 0.3, a zero gap)
+// or does not converge in VG_NEWTON_MAXIT iterations returns false and the Jacobi sweeps run as usual from the untouched G.
+// Buffers (mp x mp zero padded, mp = m rounded up to 16, row stride mp + 2): NB + {0: H0, 1: W, 2: H, 3: E / R / Gram, 4: products}.
+#define VG_NEWTON_MAXIT 6
+typedef double vg_nd4 __attribute__((ext_vector_type(4)));
+// C = epilogue(op(A) B) on the matrix cores, all matrices mp x mp (mp = m rounded up to 16, zero padded) with row stride
+// ld = mp + 2: wave w owns the 16 x 16 block w of C.  (A scalar product loop reads 16 bytes of LDS per multiply-add: 221 KB per
+// 24^3 product, 0.7 us at the LDS rate -- measured 1.4 us; the MFMA fragments need 1 byte per multiply-add.)
+// EPI 0: C = A B;  1: C = I + X + 0.5 A B (X read at C's own positions);  2: C = 1.5 I - 0.5 A B.   C must not alias A, B or X.
+template <int EPI>
+__device__ __forceinline__ void vg_nt_mm(double* C, const double* A, int sa_i, int sa_k, const double* B, int mp, int ld, const double* X = nullptr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = mp >> 4;
+    const int fi = lane & 15, fk = lane >> 4;
+    for (int blk = wave; blk < nb * nb; blk += blockDim.x >> 6) {
+        const int bi = blk / nb, bj = blk - bi * nb;
+        const double* a = A + (bi * 16 + fi) * sa_i + fk * sa_k;
+        const double* b = B + fk * ld + bj * 16 + fi;
+        vg_nd4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+        for (int k0 = 0; k0 < mp; k0 += 16) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = a[(k0 + 4 * u) * sa_k]; bv[u] = b[(k0 + 4 * u) * ld]; }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = bi * 16 + fk + 4 * r, col = bj * 16 + fi;
+            double v = acc0[r] + acc1[r];
+            if (EPI == 1) v = ((row == col) ? 1.0 : 0.0) + X[row * ld + col] + 0.5 * v;
+            if (EPI == 2) v = ((row == col) ? 1.5 : 0.0) - 0.5 * v;
+            C[row * ld + col] = v;
+        }
+    }
+    __syncthreads();
+}
+// (buffers: five mp x ld areas behind NB; on success *Hout / *Wout point at the diagonalised matrix and at W, whose COLUMNS are
+//  the eigenvectors)
+__device__ __forceinline__ bool vg_newton_diag(int m, const double* Wpk, double* NB, double thr, int* flags /* 4 ints of LDS */, int& iters,
+                                               const double** Hout, const double** Wout) {
+    const int mp = (m + 15) & ~15, ld = mp + 2, sz = mp * ld, tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    double *H0 = NB, *Wn = NB + sz, *H = NB + 2 * sz, *E = NB + 3 * sz, *T = NB + 4 * sz;
+    for (int e = tid; e < sz; e += nthr) {
+        const int i = e / ld, j = e - i * ld;
+        const double v = (i < m && j < m) ? Wpk[vg_sym(i, j)] : 0.0;
+        H0[e] = v; H[e] = v;
+        Wn[e] = (i == j && i < m) ? 1.0 : 0.0;
+        E[e] = 0.0; T[e] = 0.0;
+    }
+    if (tid < 4) flags[tid] = 0;
+    __syncthreads();
+    for (int it = 0; it < VG_NEWTON_MAXIT; ++it) {
+        // E from the strict lower triangle of H (skew).  flags: [0] some element above the threshold, [1] a rotation too large,
+        // [2] some |E_ij| > 1e-5 (R = I + E + E^2/2 is then not orthogonal to rounding: a Newton-Schulz step follows),
+        // [3] some |E_ij| > 1e-8 (the E^2 term matters)
+        int fl = 0;
+        for (int i = wave; i < m; i += nw)
+            for (int j = lane; j < m; j += 64) {
+                double ev = 0.0;
+                if (i != j) {
+                    const int lo = i > j ? i : j, hi = i > j ? j : i;          // element (lo, hi) of the lower triangle
+                    const double h = H[lo * ld + hi];
+                    if (fabs(h) > thr) {
+                        const double gap = H[hi * ld + hi] - H[lo * ld + lo];  // e_(lo,hi) = h / (h_hihi - h_lolo)
+                        const double q = h / gap, aq = fabs(q);
+                        fl |= 1;
+                        if (!(aq < 0.3)) fl |= 2;                              // also catches NaN / inf
+                        if (aq > 1e-5) fl |= 4;
+                        if (aq > 1e-8) fl |= 8;
+                        ev = i > j ? q : -q;
+                    }
+                }
+                E[i * ld + j] = ev;
+            }
+        if (fl & 1) atomicOr(&flags[0], 1);
+        if (fl & 2) atomicOr(&flags[1], 1);
+        if (fl & 4) atomicOr(&flags[2], 1);
+        if (fl & 8) atomicOr(&flags[3], 1);
+        __syncthreads();
+        const int f0 = flags[0], f1 = flags[1], f2 = flags[2], f3 = flags[3];
+        __syncthreads();
+        if (tid < 4) flags[tid] = 0;
+        if (f1) return false;
+        if (!f0) { iters = it; *Hout = H; *Wout = Wn; return true; }
+        double* R = E;
+        if (f3) { vg_nt_mm<1>(T, E, ld, 1, E, mp, ld, E); R = T; }              // R = I + E + E^2 / 2   (else R = I + E: below)
+        else {
+            for (int i = tid; i < mp; i += nthr) E[i * ld + i] = 1.0;
+            __syncthreads();
+        }
+        double* WR = (R == T) ? E : T;                                         // the free buffer
+        vg_nt_mm<0>(WR, Wn, ld, 1, R, mp, ld);                                 // W R
+        double* Wnew = WR;
+        if (f2) {
+            double* S = (WR == E) ? T : E;
+            vg_nt_mm<2>(S, WR, 1, ld, WR, mp, ld);                             // 1.5 I - 0.5 (W R)^T (W R)
+            vg_nt_mm<0>(Wn, WR, ld, 1, S, mp, ld);                             // W <- (W R) (1.5 I - 0.5 Gram)
+            Wnew = Wn;
+        }
+        // (W moved into another buffer when the Newton-Schulz step was skipped: rotate the roles instead of copying)
+        double* spare = (Wnew == Wn) ? nullptr : Wn;
+        double* P = (Wnew == E) ? T : ((Wnew == T) ? E : T);                   // a buffer that is neither W nor H0 / H
+        vg_nt_mm<0>(P, H0, ld, 1, Wnew, mp, ld);                               // H0 W
+        vg_nt_mm<0>(H, Wnew, 1, ld, P, mp, ld);                                // H <- W^T H0 W
+        if (spare) {                                                           // Wn <-> the buffer that now holds W
+            if (Wnew == E) E = spare; else T = spare;
+            Wn = Wnew;
+        }
+    }
+    return false;
+}
+
 #ifdef VG_EIG_RT
 #define RT(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); reinterpret_cast<unsigned long long*>(J.gwork)[(long)J.m * J.m + 8 + (i)] = t_;   /* past the polish matrix E */ } } while (0)
 #else
@@ -462,7 +588,24 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
     int nlog = 0, sweeps = 0, status = 0;
     bool converged = false, polished = false;
     RT(1);
-    if (INLDS && fast && !J.sparse_first)   // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
+    bool direct = false;
+    double* NB = nullptr;
+    const double *ntH = nullptr, *ntW = nullptr;
+    if (INLDS && J.newton && !J.Qt0 && m <= VG_EIG_NEWTON_MAX_M) {
+        NB = W + 2 * ((m2 * (m2 + 1)) >> 1);
+        int iters = 0;
+        __shared__ int ntflags[4];
+        direct = vg_newton_diag(m, W, NB, thr, ntflags, iters, &ntH, &ntW);
+        if (direct) {
+            const int ldn = ((m + 15) & ~15) + 2;
+            for (int i = tid; i < m; i += nthr) W[vg_tri(i) + i] = ntH[i * ldn + i];
+            converged = true;
+            sweeps = iters;
+        }
+        if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
+        __syncthreads();
+    }
+    if (INLDS && fast && !J.sparse_first && !direct)   // dense sweeps with fixed addresses; the second copy of G follows the first in LDS
         W = vg_jacobi_fast(J, W, W + ((m2 * (m2 + 1)) >> 1), cs, reinterpret_cast<double*>(pq), nact_s, thr, nlog, sweeps,
                            status, converged, polished);
 
@@ -638,6 +781,19 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
             __hip_atomic_store(&J.perm[i], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         J.lam[rank] = li;
+        if (direct) reinterpret_cast<int*>(pq)[i] = rank;     // (the pair records are free now)
+    }
+    if (direct) {                                             // eigenvector i = column i of the Newton iterate
+        __syncthreads();
+        const int* rk = reinterpret_cast<const int*>(pq);
+        const int ldn = ((m + 15) & ~15) + 2;
+        const double* Wn = ntW;
+        for (int idx = tid; idx < m * m; idx += nthr) {
+            const int i = idx / m, j = idx - i * m;
+            const double v = Wn[j * ldn + i];
+            J.Qt[rk[i] * m + j] = v;
+            if (J.Qt2) J.Qt2[rk[i] * m + j] = v;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ranks are at the L2 before DONE is published
     __syncthreads();
@@ -650,7 +806,7 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
         J.counters[1] = sweeps | (nrank << 8);               // numerical rank rides above the sweep count
         J.counters[2] = status;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE | (polished ? VG_EIG_POLISH : 0), __ATOMIC_RELAXED,
+        __hip_atomic_store(&J.counters[3], nlog | VG_EIG_DONE | (polished ? VG_EIG_POLISH : 0) | (direct ? VG_EIG_DIRECT : 0), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     RT(4);
@@ -712,7 +868,8 @@ __device__ __forceinline__ void vg_replay_body(const VgEigJob& J, int cblock, in
         const bool done = (pw & VG_EIG_DONE) != 0;
         if (pw & 0x20000000) break;                          // producer never showed up (timeout)
         polish = done && (pw & VG_EIG_POLISH);
-        const int published = pw & 0x0fffffff;
+        if (done && (pw & VG_EIG_DIRECT)) return;             // uniform: the producer wrote Q^T itself
+        const int published = pw & 0x07ffffff;
         const int nr = min(rounds_per_chunk, published - consumed);
         if (nr > 0) {
             for (int idx = tid; idx < nr * half; idx += nthr) {
@@ -1531,6 +1688,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const
     static const char* fs_env = getenv("VGGP_EIG_FAST_SWITCH");      // tuning / A-B switch (0 disables the dense phase)
     static const char* tol_env = getenv("VGGP_EIG_TOL");
     static const bool no_polish = getenv("VGGP_EIG_NO_POLISH") != nullptr;
+    static const bool no_newton = getenv("VGGP_EIG_NO_NEWTON") != nullptr;
     size_t lds = 0;
     int maxm2 = 0;
     for (int j = 0; j < njobs; ++j) maxm2 = jobs[j].m + 1 > maxm2 ? jobs[j].m + 1 : maxm2;
@@ -1543,6 +1701,7 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const
         if (fs_env) a.job[j].fast_switch = atoi(fs_env);
         if (tol_env) a.job[j].tol = atof(tol_env);
         if (no_polish) a.job[j].polish = 0;
+        if (no_newton) a.job[j].newton = 0;
         const int m = jobs[j].m;
         if (m < 1 || m > 256) return hipErrorInvalidValue;
         const int m2 = m + (m & 1);
@@ -1558,6 +1717,8 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const
             need = (((Mp * (Mp + 1) / 2 + 1) & ~size_t(1)) + np * VG_BJ_SLOT) * sizeof(double);
             rp = (Mp * 17 + 2 + np * 1024) * sizeof(double);
         }
+        if (a.use_lds[j] && a.job[j].newton && !jobs[j].Qt0 && m <= VG_EIG_NEWTON_MAX_M && !(jobs[j].block && m <= VG_BJ_MAX_M))
+            need = (size_t)m2 * (m2 + 1) * sizeof(double) + 5 * (size_t)((m + 15) & ~15) * (((m + 15) & ~15) + 2) * sizeof(double);      // two packed copies + five padded buffers
         if (rp > need) need = rp;
         if (need > lds) lds = need;
         if (m2 > maxm2) maxm2 = m2;
