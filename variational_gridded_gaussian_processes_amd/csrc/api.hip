@@ -602,7 +602,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         vg_gemm_init(&g);
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            vg_gemm_add(&g, d.Fp, d.m, 1, G0[k], d.m, 1, d.Zs, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);       // Z = V G
+            vg_gemm_add(&g, d.Fp, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);           // S G (rows < r: Z = V G)
             if (from_slabs && ghn[k] > 1) {
                 vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
                 vg_gemm_add(&g, d.Id, d.m, 1, H0[k], d.m, 1, gdst[k] + (long)d.m * d.m, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
@@ -615,7 +615,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
-            qj[k] = VgRowQrJob{d.Zs, d.V1s, d.sub_r, d.m, d.Fp + r * d.m, d.E + r * d.m, (long)(d.m - r) * d.m};   // + E[r:] <- S[r:]
+            qj[k] = VgRowQrJob{d.TM, d.V1s, d.sub_r, d.m, d.Fp + r * d.m, d.E + r * d.m, (long)(d.m - r) * d.m};   // + E[r:] <- S[r:]
         }
         VG_HIP(vg_rowqr_launch(qj, 2, st, ride ? &c->ride_proj : nullptr));      // + rider: S = [B2;V2] Y
         if (ride) ride_stage = 1;
@@ -628,25 +628,30 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_add(&g, d.Fp + r * d.m, d.m, 1, d.V1s, 1, d.m, d.TH, (int)r, (int)(d.m - r), (int)r, d.m);           // P = S[r:] V1^T
         }
         VG_HIP(vg_gemm_launch(&g, st));
-        vg_gemm_init(&g);
+        VG_MARK(10);
+        // The Ritz matrix H = T V1^T is formed by the Ritz launch's producer workgroups themselves (VgEigJob::Hl/Hr).  The
+        // complement rows do not wait for the Ritz vectors: E[r:] = S[r:] - P V1 and, by linearity,
+        // (E G)[r:] = (S G)[r:] - P T -- both ride in the Ritz launch as extra workgroups (with [C;C1;C2] in the fused step).
+        VgGemmBatch gx;
+        vg_gemm_init(&gx);
+        if (ride) gx = c->ride_cc;
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             const long r = d.sub_r;
-            vg_gemm_add(&g, d.Zs, d.m, 1, d.V1s, 1, d.m, d.Hs, (int)r, (int)r, (int)r, d.m);                          // H = T V1^T
-            vg_gemm_add(&g, d.TH, r, 1, d.V1s, d.m, 1, d.E + r * d.m, d.m, (int)(d.m - r), d.m, (int)r, 1, 0, 1, 0, -1.0, 1);   // E[r:] -= P V1
+            vg_gemm_add(&gx, d.TH, r, 1, d.V1s, d.m, 1, d.E + r * d.m, d.m, (int)(d.m - r), d.m, (int)r, 1, 0, 1, 0, -1.0, 1);    // E[r:] -= P V1
+            vg_gemm_add(&gx, d.TH, r, 1, d.Zs, d.m, 1, d.TM + r * d.m, d.m, (int)(d.m - r), d.m, (int)r, 1, 0, 1, 0, -1.0, 1);   // (S G)[r:] -= P T
         }
-        VG_HIP(vg_gemm_launch(&g, st));
-        VG_MARK(10);
         VgEigJob sj[2];
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
-            sj[k] = VgEigJob{d.Hs, d.lam_s, d.Ws, nullptr, d.gwork2, d.rotlog2, d.roundlog2, d.counters2, d.sub_r, d.max_rounds,
+            sj[k] = VgEigJob{nullptr, d.lam_s, d.Ws, nullptr, d.gwork2, d.rotlog2, d.roundlog2, d.counters2, d.sub_r, d.max_rounds,
                              (long)vg_eigh_log_bytes(d.m), 0};
+            sj[k].Hl = d.Zs; sj[k].Hr = d.V1s; sj[k].hk = d.m;
             sj[k].perm = d.perm2;
             sj[k].err = d.status + 1;
             sj[k].newton = 1;
         }
-        VG_HIP(vg_eigh_launch(sj, 2, st, ride ? &c->ride_cc : nullptr));                              // Ritz pairs (+ rider: [C;C1;C2])
+        VG_HIP(vg_eigh_launch(sj, 2, st, &gx));                              // Ritz pairs (+ riders)
         if (ride) ride_stage = 2;
         VG_MARK(11);
         vg_gemm_init(&g);
@@ -655,8 +660,6 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             const long r = d.sub_r;
             vg_gemm_add(&g, d.Ws, r, 1, d.V1s, d.m, 1, d.E, d.m, (int)r, d.m, (int)r);                                // E[:r] = W V1
             vg_gemm_add(&g, d.Ws, r, 1, d.Zs, d.m, 1, d.TM, d.m, (int)r, d.m, (int)r);                                 // (E G)[:r] = W T
-            vg_gemm_add(&g, d.E + r * d.m, d.m, 1, Gr[k], d.m, 1, d.TM + r * d.m, d.m, (int)(d.m - r), d.m, d.m, 1, 0,
-                        grn[k], ghs[k]);                                                                                 // (E G)[r:]
         }
         VG_HIP(vg_gemm_launch(&g, st));
         vg_gemm_init(&g);

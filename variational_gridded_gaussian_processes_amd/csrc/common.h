@@ -176,6 +176,9 @@ struct VgEigJob {
     int polish = 1;        // dense phase: replace the remaining sweeps by a first-order polish when its a-priori bound allows
     int* err = nullptr;    // optional device word the replay workgroups OR a 1 into when they give up waiting for the producer
     int polish0 = 0;       // also try the polish before the first sweep (the start basis was refined by vg_refine_launch)
+    const double* Hl = nullptr;  // the matrix as a product G = Hl Hr^T (m x hk row-major factors; LDS variant only): formed by the
+    const double* Hr = nullptr;  // producer workgroup itself on the matrix cores; `G` is then ignored
+    int hk = 0;
     int newton = 0;        // nearly diagonal small problem (m <= 48, no start basis): try the Newton start first (vg_newton_diag)
     int sparse_first = 0;  // skip the dense phase: the start basis already block-diagonalises G (subspace start), a few elements remain
 };

@@ -546,7 +546,74 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
     // load the lower triangle (zero padded) and the Frobenius norm
     // (a wave takes whole rows -- coalesced, no integer division -- and four rows' loads are in flight together)
     double ss = 0.0;
-    {
+    if (INLDS && J.Hl && J.Hr) {
+        // the matrix is given as a product: G = Hl Hr^T (m x hk factors, row-major; the Ritz matrix H = (V1 G) V1^T of the
+        // subspace start) -- one 16 x 16 block of the lower triangle per wave on the matrix cores, operands straight from global
+        // memory, 8 k-steps of loads in flight; saves the GEMM launch that used to form it
+        const int lane_ = tid & 63, wave_ = tid >> 6, nw_ = nthr >> 6, fi = lane_ & 15, fk = lane_ >> 4;
+        const int nb = (m2 + 15) >> 4, hk = J.hk;
+        // small problems: both factors are staged in LDS first (behind the packed copies, where the Newton start's buffers go
+        // later) -- one coalesced batch of loads for the whole workgroup instead of four dependent batches of 32-byte segments
+        // per wave (measured: 10 us -> 3 us for the 24 x 128 factors)
+        const bool staged = m <= VG_EIG_NEWTON_MAX_M && hk <= 128;
+        const int ldh = hk + 2, mp = nb * 16;
+        double* Tl = W + 2 * ((m2 * (m2 + 1)) >> 1);
+        double* Vl = Tl + mp * ldh;
+        if (staged) {
+            double tv[8], vv[8];                                   // mp * hk <= 48 * 128 = 6 * 1024 elements per factor
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * nthr;
+                const bool okl = idx < m * hk;
+                tv[u] = okl ? J.Hl[idx] : 0.0;
+                vv[u] = okl ? J.Hr[idx] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * nthr;
+                if (idx < mp * hk) {
+                    const int i = idx / hk, k = idx - i * hk;
+                    Tl[i * ldh + k] = tv[u];
+                    Vl[i * ldh + k] = vv[u];
+                }
+            }
+        }
+        for (int i = tid; i < ((m2 * (m2 + 1)) >> 1); i += nthr) W[i] = 0.0;
+        __syncthreads();
+        for (int blk = wave_; blk < ((nb * (nb + 1)) >> 1); blk += nw_) {
+            int bi = 0, rest = blk;
+            while (rest > bi) { rest -= bi + 1; ++bi; }
+            const int bj = rest;
+            const int ra = bi * 16 + fi, rb = bj * 16 + fi;
+            const double* pa = staged ? Tl + ra * ldh + fk : J.Hl + (long)(ra < m ? ra : 0) * hk + fk;
+            const double* pb = staged ? Vl + rb * ldh + fk : J.Hr + (long)(rb < m ? rb : 0) * hk + fk;
+            const double ma = (staged || ra < m) ? 1.0 : 0.0, mb = (staged || rb < m) ? 1.0 : 0.0;
+            vg_nd4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < hk; k0 += 32) {
+                double av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 4 * u;
+                    av[u] = (k + fk < hk) ? pa[k] * ma : 0.0;
+                    bv[u] = (k + fk < hk) ? pb[k] * mb : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = bi * 16 + fk + 4 * r4, col = bj * 16 + fi;
+                if (row < m && col <= row) {
+                    const double v = acc0[r4] + acc1[r4];
+                    W[vg_tri(row) + col] = v;
+                    ss += (row == col) ? v * v : 2.0 * v * v;
+                }
+            }
+        }
+    } else {
         const int lane_ = tid & 63, wave_ = tid >> 6, nw_ = nthr >> 6;
         for (int i0 = wave_; i0 < m2; i0 += 4 * nw_) {
             double v[4][4];
@@ -1719,6 +1786,10 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const
         }
         if (a.use_lds[j] && a.job[j].newton && !jobs[j].Qt0 && m <= VG_EIG_NEWTON_MAX_M && !(jobs[j].block && m <= VG_BJ_MAX_M))
             need = (size_t)m2 * (m2 + 1) * sizeof(double) + 5 * (size_t)((m + 15) & ~15) * (((m + 15) & ~15) + 2) * sizeof(double);      // two packed copies + five padded buffers
+        if (a.use_lds[j] && jobs[j].Hl && m <= VG_EIG_NEWTON_MAX_M && jobs[j].hk <= 128) {      // staging area of the two factors
+            const size_t stg = (size_t)m2 * (m2 + 1) * sizeof(double) + 2 * (size_t)((m2 + 15) & ~15) * (jobs[j].hk + 2) * sizeof(double);
+            if (stg > need) need = stg;
+        }
         if (rp > need) need = rp;
         if (need > lds) lds = need;
         if (m2 > maxm2) maxm2 = m2;
