@@ -237,6 +237,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.dK0 = b.take<double>(m * m);
         d.L0 = b.take<double>(m * m);
         d.Linv0 = b.take<double>(m * m);
+        d.Dinv0 = b.take<double>(((m + 15) / 16) * 256);
         d.X = b.take<double>(m * m);
         d.chol_scratch = b.take<double>(m * (m + 1));
         d.RQ = b.take<double>(m * m);
@@ -423,6 +424,10 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     //    zeroes the status words, the jitter-level flags and the Jacobi progress words of the step.
     VgFactorJob fj[2];
     VgCholJob cj[2];
+    // m <= 128: the Cholesky launch only leaves L and the inverses of its 16 x 16 diagonal blocks; L^{-1} itself (wanted by
+    // Mk = X L^{-T} and by the read-outs) comes out of the substitution launch as one more right-hand side, the identity
+    static const bool chol_legacy = getenv("VGGP_CHOL_LEGACY") != nullptr;
+    const bool dinv_path = d1.m <= VG_TRSM_BLK && d2.m <= VG_TRSM_BLK && !chol_legacy;
     VgClearArgs clr;
     clr.n = 0;
     for (int k = 0; k < 2; ++k) {
@@ -431,7 +436,8 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         clr.ptr[clr.n] = d.status; clr.nwords[clr.n++] = 2;
         clr.ptr[clr.n] = reinterpret_cast<int*>(d.chol_scratch); clr.nwords[clr.n++] = 16;     // jitter-level flags
         clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 8;                                  // Jacobi progress words (counters, counters2)
-        cj[k] = VgCholJob{d.K0, d.L0, d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
+        cj[k] = VgCholJob{d.K0, d.L0, dinv_path ? nullptr : d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
+        cj[k].Dinv_out = d.Dinv0;
     }
     VG_HIP(vg_factor_build_launch(fj, 2, c->d_htheta, st, c->theta, &clr));
     VG_MARK(0);
@@ -446,14 +452,20 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     {
         const bool big = d1.m > VG_TRSM_BLK || d2.m > VG_TRSM_BLK;
         if (!big) {
-            VgTrsmJob tj[6];
+            VgTrsmJob tj[8];
             int nt = 0;
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
                 const long mn = (long)d.m * d.n;
+                const double* dv = dinv_path ? d.Dinv0 : d.Linv0;
+                const long dblk = dinv_path ? 256 : 16L * d.m + 16, dld = dinv_path ? 16 : d.m;
                 for (int b = 0; b < 2; ++b)
-                    tj[nt++] = VgTrsmJob{d.L0, d.Linv0, d.AD + b * mn, d.BV + b * mn, d.m, 16L * d.m + 16, d.m, d.n, 1, d.n, 1, d.n, d.m, 0};
-                tj[nt++] = VgTrsmJob{d.L0, d.Linv0, d.dK0, d.X, d.m, 16L * d.m + 16, d.m, d.m, 1, d.m, 1, d.m, d.m, 0};
+                    tj[nt++] = VgTrsmJob{d.L0, dv, d.AD + b * mn, d.BV + b * mn, d.m, dblk, dld, d.n, 1, d.n, 1, d.n, d.m, 0};
+                tj[nt++] = VgTrsmJob{d.L0, dv, d.dK0, d.X, d.m, dblk, dld, d.m, 1, d.m, 1, d.m, d.m, 0};
+                if (dinv_path) {
+                    tj[nt] = VgTrsmJob{d.L0, dv, d.L0, d.Linv0, d.m, dblk, dld, d.m, 1, d.m, 1, d.m, d.m, 0};      // Linv0 = L0^{-1} I
+                    tj[nt++].rhs_ident = 1;
+                }
             }
             VG_HIP(vg_trsm_launch(tj, nt, st));
         } else {

@@ -504,11 +504,14 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
     if (report_fail) {
         if (tid == 0) { *J.status = VGGP_ENOTPD; if (J.jitter_out) *J.jitter_out = -1.0; }
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int idx = tid; idx < m * m; idx += nthr) { J.L[(long)(idx / m) * ldl + idx % m] = qnan; J.Linv[idx] = qnan; }
+        for (int idx = tid; idx < m * m; idx += nthr) { J.L[(long)(idx / m) * ldl + idx % m] = qnan; if (J.Linv) J.Linv[idx] = qnan; }
+        if (J.Dinv_out) for (int idx = tid; idx < nb * VG_CB * VG_CB; idx += nthr) J.Dinv_out[idx] = qnan;
     }
     if (!winner) return;
     if (tid == 0 && J.jitter_out) *J.jitter_out = jit;
     CM(T[3]);
+    // the inverses of the 16 x 16 diagonal blocks, [nb][16][16]: all a substitution (trsm.hip) needs of the inverse
+    if (J.Dinv_out) for (int idx = tid; idx < nb * VG_CB * VG_CB; idx += nthr) J.Dinv_out[idx] = Dinv[idx];
 
     // ---- L out (the upper block triangle of Lm is about to receive X) ----
     for (int i = wave; i < m; i += (nthr >> 6))
@@ -518,6 +521,9 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
             if (j < m) J.L[(long)i * ldl + j] = (j <= i) ? Lm[i * VG_CLD + j] : 0.0;
         }
     CM(T[4]);
+    // (no full inverse wanted: the step takes L^{-1} from the substitution kernel -- an identity right-hand side in the same
+    //  launch as B = L^{-1} A -- which removes this phase and the store below, 12 us of 58 at m = 128, from the critical path)
+    if (!J.Linv) return;
     // ---- X = L^{-1}: block column bj by wave bj, rows top-down; X[bi][bj] is kept at block position (bj, bi) ----
     for (int bj = wave; bj < nb; bj += (nthr >> 6)) {
         for (int bi = bj + 1; bi < nb; ++bi) {
@@ -614,6 +620,8 @@ hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
     static const bool legacy = getenv("VGGP_CHOL_LEGACY") != nullptr;      // A/B switch: register-resident column kernel
     bool all_fast = !legacy;
     for (int j = 0; j < njobs; ++j) all_fast = all_fast && jobs[j].m >= 1 && jobs[j].m <= VG_CHOL_FAST_MAX_M;
+    for (int j = 0; j < njobs; ++j)
+        if (!jobs[j].Linv && !all_fast) return hipErrorInvalidValue;      // only the MFMA path can leave the inverse out
     if (all_fast) {
         for (int j = 0; j < njobs; ++j) {
             a.job[j] = jobs[j];

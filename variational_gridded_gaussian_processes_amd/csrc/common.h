@@ -129,6 +129,8 @@ struct VgCholJob {
     int m;
     int ldk = 0, ldl = 0; // row strides of K and L when they are sub-blocks of larger matrices
     int only_level0 = 0;  // 1: factor as is (no jitter levels); used for the well-conditioned Sigma~ blocks
+    double* Dinv_out = nullptr;   // optional [ceil(m/16)][16][16]: inverses of the diagonal blocks (m <= 128 path); with Linv = nullptr
+                                  // the full inverse is not formed at all
 };
 hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st);
 hipError_t vg_chol_setup();   // opt-in to large dynamic LDS

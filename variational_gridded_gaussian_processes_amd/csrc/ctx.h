@@ -9,6 +9,7 @@ struct VgDim {
     int kind = 0, basis = 0, n = 0, m = 0;
     double *x = nullptr, *grid = nullptr;
     double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
+    double* Dinv0 = nullptr;          // [ceil(m/16)][16][16]: inverses of the diagonal blocks of L0 (left by the Cholesky launch)
     double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
     double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr, *QtPrev2 = nullptr, *U = nullptr;
     double *Ep = nullptr, *Fp = nullptr, *Wp = nullptr;      // prediction of the next start basis (finish_enqueue tail)
