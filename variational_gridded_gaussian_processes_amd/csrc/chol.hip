@@ -379,7 +379,11 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
             vg_cd4 acc = {0.0, 0.0, 0.0, 0.0};
             const double* ap = Lm + (p * VG_CB + fi) * VG_CLD + fk;
             const double* bp = Lm + (bi * VG_CB + fi) * VG_CLD + fk;
-            for (int k0 = 0; k0 < p * VG_CB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
+            // (the diagonal block, bi == p, arrives as a running Schur complement: every earlier panel subtracted its
+            //  contribution in step (3), spread over the waves -- wave 0's chain of up to 28 dependent MFMAs per panel, 8.4 us
+            //  of the factorisation's critical path at m = 128, is gone)
+            if (wave > 0)
+                for (int k0 = 0; k0 < p * VG_CB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = fk + 4 * r, i = fi;                    // D layout: row c (panel column), col i (row inside block bi)
@@ -472,6 +476,16 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
             for (int r = 0; r < 4; ++r) lt = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * r], ut[r], lt, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Lm[(bi * VG_CB + fi) * VG_CLD + p * VG_CB + fk + 4 * r] = lt[r];
+            // running Schur complement of this block row's own diagonal block: D[bi] -= L[bi][p] L[bi][p]^T.  lt[s] at lane
+            // (fi, fk) is L[16 bi + fi][16 p + fk + 4 s]: exactly the A operand AND the B operand of k-step s.
+            vg_cd4 dd = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dd = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[r], lt[r], dd, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = fk + 4 * r;
+                if (fi <= row) Lm[(bi * VG_CB + row) * VG_CLD + bi * VG_CB + fi] -= dd[r];       // stored lower
+            }
         }
         __syncthreads();
         CM(q1);
