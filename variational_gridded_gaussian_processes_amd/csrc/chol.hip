@@ -336,32 +336,35 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
 #endif
 
     // lower triangle of K (+ jitter), identity on the padding; everything above the diagonal blocks starts at zero.
-    // A wave takes whole rows (coalesced, no integer division); four rows' loads are in flight together.
+    // A wave takes whole rows (coalesced, no integer division).  ALL loads of the thread are issued before the first LDS
+    // store: K was written by the previous kernel (cold in this XCD's L2), and four dependent batches of four rows cost
+    // 5 us at m = 128 where one batch costs 2.
     {
-        const int nw = nthr >> 6;
-        for (int i0 = wave; i0 < mp; i0 += 4 * nw) {
-            double v[4][2];
+        const int nw = nthr >> 6;                      // 8 waves: rows wave, wave + 8, ... -> at most 16 rows per wave (mp <= 128)
+        double v[16][2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * nw;
+        for (int u = 0; u < 16; ++u) {
+            const int i = wave + u * nw;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int j = lane + 64 * h;
-                    double x = 0.0;
-                    if (i < m && j <= i) x = J.K[(long)i * ldk + j];
-                    v[u][h] = x;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * nw;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int j = lane + 64 * h;
-                    if (i < mp && j < mp) Lm[i * VG_CLD + j] = v[u][h] + (i == j ? (i < m ? jit : 1.0) : 0.0);
-                }
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                v[u][h] = (i < m && j <= i) ? J.K[(long)i * ldk + j] : 0.0;
             }
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = wave + u * nw;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                if (i < mp && j < mp) Lm[i * VG_CLD + j] = v[u][h] + (i == j ? (i < m ? jit : 1.0) : 0.0);
+            }
+        }
+        for (int i = wave + 16 * nw; i < mp; i += nw)      // (fewer than 8 waves: never taken with the 512-thread launch)
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                if (j < mp) Lm[i * VG_CLD + j] = ((i < m && j <= i) ? J.K[(long)i * ldk + j] : 0.0) + (i == j ? (i < m ? jit : 1.0) : 0.0);
+            }
     }
     for (int idx = tid; idx < nb * VG_CB * VG_CB; idx += nthr) Dinv[idx] = 0.0;
     if (tid == 0) s_i[2] = 0;
