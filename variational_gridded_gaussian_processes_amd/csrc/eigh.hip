@@ -613,6 +613,32 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
                 }
             }
         }
+    } else if (INLDS && m2 <= 128 && nthr == 1024) {
+        // m <= 128 with the full workgroup: 16 waves x 8 rows = the whole matrix in ONE batch of loads (G comes straight from
+        // the previous kernel, cold in this XCD's L2: two dependent batches of four rows cost 4.4 us, one costs ~2.5)
+        const int lane_ = tid & 63, wave_ = tid >> 6;
+        double v[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = wave_ + 16 * u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane_ + 64 * h;
+                v[u][h] = (i < m && j <= i) ? J.G[i * m + j] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = wave_ + 16 * u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane_ + 64 * h;
+                if (i < m2 && j <= i) {
+                    W[vg_tri(i) + j] = v[u][h];
+                    ss += (i == j) ? v[u][h] * v[u][h] : 2.0 * v[u][h] * v[u][h];
+                }
+            }
+        }
     } else {
         const int lane_ = tid & 63, wave_ = tid >> 6, nw_ = nthr >> 6;
         for (int i0 = wave_; i0 < m2; i0 += 4 * nw_) {
@@ -835,18 +861,24 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
     double* dg = reinterpret_cast<double*>(cs);         // the diagonal, staged contiguously (the rotation array is free now)
     for (int i = tid; i < m; i += nthr) dg[i] = W[vg_tri(i) + i];
     __syncthreads();
-    for (int i = tid; i < m; i += nthr) {
+    // rank of eigenvalue i = number of eigenvalues ahead of it: 8 lanes per eigenvalue share the count (m <= 128 with 1024
+    // threads; a lone lane per eigenvalue walks all m entries: 3 us at m = 128), then the lane group's leader writes
+    const int rgrp = (m * 8 <= nthr) ? 8 : 1;
+    for (int i = tid / rgrp; i < m; i += nthr / rgrp) {
+        const int part = tid % rgrp;
         const double li = dg[i];
         int rank = i;
         if (J.perm) {
             rank = 0;
 #pragma unroll 8
-            for (int j = 0; j < m; ++j) {
+            for (int j = part; j < m; j += rgrp) {
                 const double lj = dg[j];
                 rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
             }
-            __hip_atomic_store(&J.perm[i], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rgrp == 8) { rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2); rank += __shfl_xor(rank, 4); }
+            if (part == 0) __hip_atomic_store(&J.perm[i], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (part != 0) continue;
         J.lam[rank] = li;
         if (direct) reinterpret_cast<int*>(pq)[i] = rank;     // (the pair records are free now)
     }
@@ -864,11 +896,15 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ranks are at the L2 before DONE is published
     __syncthreads();
-    if (tid == 0) {
+    int nrank = 0;
+    if (tid < 64) {                                          // wave 0: largest eigenvalue and numerical rank by wave reductions
         double lmax = 0.0;
-        for (int j = 0; j < m; ++j) lmax = fmax(lmax, dg[j]);
-        int nrank = 0;
-        for (int j = 0; j < m; ++j) nrank += dg[j] > VG_EIG_RANK_CUT * lmax ? 1 : 0;
+        for (int j = tid; j < m; j += 64) lmax = fmax(lmax, dg[j]);
+        for (int off = 32; off > 0; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
+        for (int j = tid; j < m; j += 64) nrank += dg[j] > VG_EIG_RANK_CUT * lmax ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) nrank += __shfl_xor(nrank, off);
+    }
+    if (tid == 0) {
         J.counters[0] = nlog;
         J.counters[1] = sweeps | (nrank << 8);               // numerical rank rides above the sweep count
         J.counters[2] = status;
