@@ -443,7 +443,18 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     VG_MARK(0);
 
     // 2. Cholesky (+ jitter schedule) and explicit inverse of both factors
-    VG_HIP(vg_chol_launch(cj, 2, st));
+    // The Newton-Schulz step of the predicted start basis, Fp += -0.5 Wp Ep (operands left by the previous step's tail, see
+    // finish_enqueue), needs nothing of this step: it rides in the Cholesky launch (8 workgroups on 256 CUs) when that is the
+    // MFMA kernel, otherwise in a GEMM launch further down.
+    const bool ns_on_chol = extrap && apply_ns && dinv_path;
+    VgGemmBatch gns;
+    vg_gemm_init(&gns);
+    if (ns_on_chol)
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&gns, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
+        }
+    VG_HIP(vg_chol_launch(cj, 2, st, ns_on_chol ? &gns : nullptr));
     VG_MARK(1);
 
     // 3. B|V = L0^{-1} [A0|dA0],  X = L0^{-1} dK0  by blocked substitution on the matrix cores (trsm.hip; the 16 x 16
@@ -504,7 +515,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     // W = Qpred Qpred^T (Wp); the Newton-Schulz step Fp += -0.5 W Qpred rides in this launch (see the tail of finish_enqueue)
     // -- or in the Gram launch when the projection itself is deferred
     auto add_ns = [&](VgGemmBatch* b) {
-        if (extrap && apply_ns)
+        if (extrap && apply_ns && !ns_on_chol)
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
                 vg_gemm_add(b, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);

@@ -18,7 +18,7 @@
 //     through a double-buffered LDS row, every thread updates its own elements in registers.
 // Generic path (m > 128): the matrix lives in an L2-resident global scratch, one workgroup tries the levels in
 // order (slow; only used by the building-block API for large matrices).
-#include "common.h"
+#include "gemm_body.h"
 
 #include <cstdlib>
 
@@ -590,15 +590,20 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
 #endif
 }
 
-__global__ __launch_bounds__(512) void vg_chol_mfma_kernel(const VgCholArgs a) {
+// `rider`: optional GEMM batch executed by extra workgroups of the launch (linear block ids >= 4 * njobs), see eigh.hip
+__global__ __launch_bounds__(512) void vg_chol_mfma_kernel(const VgCholArgs a, const VgGemmBatch rider) {
     extern __shared__ double vg_cm_dyn[];
+    if ((int)blockIdx.x >= 4 * a.njobs) {
+        vg_gemm_body<64, 16, 512>(rider, vg_cm_dyn, blockIdx.x - 4 * a.njobs);
+        return;
+    }
     __shared__ double Db[16 * 17];
     __shared__ double colbuf[16 * 16];
     __shared__ double xrow[2 * 16];
     __shared__ double sdv[16];
     __shared__ int s_i[4];
-    const VgCholJob& J = a.job[blockIdx.y];
-    const int lvl = blockIdx.x;
+    const VgCholJob& J = a.job[blockIdx.x >> 2];
+    const int lvl = blockIdx.x & 3;
     if (J.only_level0 && lvl > 0) return;
     const int nb = (J.m + VG_CB - 1) / VG_CB, mp = nb * VG_CB;
     vg_chol_mfma(J, lvl, vg_cm_dyn, vg_cm_dyn + mp * VG_CLD, Db, colbuf, xrow, sdv, s_i);
@@ -629,7 +634,7 @@ hipError_t vg_chol_setup() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
 }
 
-hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
+hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider) {
     if (njobs < 1 || njobs > 4) return hipErrorInvalidValue;
     VgCholArgs a;
     a.njobs = njobs;
@@ -647,9 +652,17 @@ hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st) {
             const size_t need = (mp * VG_CLD + mp * VG_CB) * sizeof(double);
             if (need > lds) lds = need;
         }
-        hipLaunchKernelGGL(vg_chol_mfma_kernel, dim3(4, njobs), dim3(512), lds, st, a);
+        VgGemmBatch rb;
+        rb.nprob = 0; rb.total_tiles = 0;
+        if (rider && rider->nprob > 0 && rider->total_tiles > 0) {
+            rb = *rider;
+            const size_t rl = 2 * VgTile<64, 16>::TILE * sizeof(double);
+            if (rl > lds) lds = rl;
+        }
+        hipLaunchKernelGGL(vg_chol_mfma_kernel, dim3(4 * njobs + rb.total_tiles), dim3(512), lds, st, a, rb);
         return hipGetLastError();
     }
+    if (rider && rider->nprob > 0) return hipErrorInvalidValue;      // (callers check vg_chol_can_ride first)
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         if (jobs[j].m > 1024 || jobs[j].m < 1) return hipErrorInvalidValue;

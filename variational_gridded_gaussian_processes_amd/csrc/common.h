@@ -132,7 +132,8 @@ struct VgCholJob {
     double* Dinv_out = nullptr;   // optional [ceil(m/16)][16][16]: inverses of the diagonal blocks (m <= 128 path); with Linv = nullptr
                                   // the full inverse is not formed at all
 };
-hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st);
+struct VgGemmBatch;
+hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);   // rider: m <= 128 path only
 hipError_t vg_chol_setup();   // opt-in to large dynamic LDS
 
 // ---- triangular solves by substitution (trsm.hip) -------------------------------------------------------------------
