@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   stages_us         per-launch-group breakdown of one step (HIP events on the launch stream, plain launches)
   cold_ms_per_step  the same loop with the eigensolver's warm start off
   m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
+  slab_1024x4096    the per-rank shape of BASELINE configs[3]: ms per step, and the projection kernel's MFMA fraction at that size
   kron_solve        BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
   factor_build      HBM-write rate of the factor kernel at m = n = 8192
   cpu_baseline      oracle/kron.py (the structured CPU twin, "port") timed on the host cores
@@ -147,7 +148,7 @@ def dense_literal_timing(kind, theta):
 def source_sha():
     """Identity of the projection kernel's source: PMC traffic numbers are only reported while they were collected on this."""
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in ("gemm.hip", "gemm_body.h"):
         with open(os.path.join(ROOT, "variational_gridded_gaussian_processes_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -325,6 +326,9 @@ def main():
             "elbo_last": elbo,
             "jacobi": {"sweeps": info["sweeps"], "rounds": info["rounds"], "jitter": info["jitter"], "polished": info.get("polished")},
             "stages_us": stages_us,
+            "stages_note": ("HIP events around plain launches in the library's profiling mode, where every launch group is its own "
+                            "launch; in the timed region above the step is one graph replay in which the projection of Y and the "
+                            "[C;C1;C2] products run as extra workgroups (riders) of the row-QR / Ritz launches"),
         }
         if not args.masked:
             flops = algorithmic_flops(n1, n2_loc, m, m)
@@ -350,6 +354,7 @@ def main():
             out["cold_ms_per_step"] = timed_loop(eng, Y, yy, args.kind, x1, x2, m, warm=False, steps=40, warmup=5)
             out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=40 if md < 256 else 12,
                                                     warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
+            out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
             out["kron_solve"] = kron_solve_bench(eng, 1024)
             out["factor_build"] = factor_build_bench(eng)
         if not args.no_cpu and world == 1 and not args.masked:
@@ -384,6 +389,31 @@ def timed_loop(eng, Y, yy, kind, x1, x2, m, warm, steps, warmup):
         one()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
+
+
+def slab_bench(eng, D, kind, m, n1=4096, n2=1024):
+    """BASELINE configs[3] per-rank shape (a 1024-row slab of a 4096-wide grid): ms per step of the fit loop, and the projection
+    kernel -- the step's only N-proportional launch -- timed by itself (profiling mode) at a size where its fixed costs no longer
+    dominate: 2 (2 m) n1 n2 flops against the fp64 MFMA peak."""
+    import torch
+    X, y, x1, x2 = D.gen_grid(n1, n2, seed=0)
+    del X
+    Y = torch.tensor(y.reshape(n2, n1), device=eng.device)
+    yy = float((y * y).sum())
+    ms = timed_loop(eng, Y, yy, kind, x1, x2, m, warm=True, steps=60, warmup=15)
+    opt = Adam(raw_start(), lr=0.01)
+    eng.profile(True)
+    for _ in range(20):
+        raw = opt.x
+        e, gr, info = eng.elbo_step(Y, yy, theta_from_raw(raw.copy()))
+        opt.step(-(gr / (1.0 + np.exp(-raw))))
+    stage_ms, psteps = eng.profile_read()
+    eng.profile(False)
+    us = stage_ms[PROJ] / max(psteps, 1) * 1e3
+    fl = 2.0 * (2 * m) * n1 * n2
+    return {"ms_per_step": ms, "grid_points_per_s": n1 * n2 / (ms * 1e-3), "project_kernel": eng.project_kernel_name(),
+            "project_us": us, "project_flops": fl, "project_TFLOP/s": fl / (us * 1e-6) / 1e12,
+            "project_frac_of_fp64_peak": fl / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS}
 
 
 def factor_build_bench(eng, n=8192, reps=5):
