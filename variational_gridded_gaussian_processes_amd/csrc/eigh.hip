@@ -14,6 +14,7 @@
 //   of columns of Q^T; every wave owns its columns outright, so there is no barrier per round.
 #include "gemm_body.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #define VG_EIG_TOL 1e-13         // default relative off-diagonal threshold (VgEigJob::tol)
@@ -1722,10 +1723,75 @@ hipError_t vg_identity_launch(double* A, int m, hipStream_t st) {
 
 struct VgRefineArgs { VgRefineJob job[2]; };
 __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
+    extern __shared__ double vr_dyn[];         // m <= 128: the packed lower triangle of Gw
     __shared__ double red[16];
     __shared__ double dg[256];
     const VgRefineJob& J = a.job[blockIdx.x];
     const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (m <= 128) {
+        // One batch of loads for the whole matrix (16 elements per thread, coalesced); the three passes below then run on
+        // registers and LDS.  Gw comes straight from the previous kernel: the three dependent passes over global memory of the
+        // general path below cost 27 us at m = 128, this one ~7.
+        const int mm = m * m;
+        double g[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int idx = tid + u * 1024; g[u] = idx < mm ? J.Gw[idx] : 0.0; }
+        double ss = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = tid + u * 1024;
+            if (idx < mm) {
+                const int i = idx / m, j = idx - i * m;
+                ss += g[u] * g[u];
+                if (j <= i) vr_dyn[vg_tri(i) + j] = g[u];
+                if (i == j) dg[i] = g[u];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        double fro = 0.0;
+        for (int w = 0; w < 16; ++w) fro += red[w];
+        const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
+        __syncthreads();
+        // every thread forms the quotient of ITS elements from the lower-triangle value (E is exactly skew), coalesced stores
+        double e[16], mE = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = tid + u * 1024;
+            e[u] = 0.0;
+            if (idx < mm) {
+                const int i = idx / m, j = idx - i * m;
+                if (i != j) {
+                    const int lo = i > j ? i : j, hi = i > j ? j : i;
+                    const double gl = vr_dyn[vg_tri(lo) + hi];
+                    if (fabs(gl) > thr) {
+                        const double q = gl / (dg[lo] - dg[hi]);
+                        mE = fmax(mE, fabs(q));
+                        if (!(fabs(q) <= VG_POLISH_EMAX)) mE = 1e300;          // NaN / inf
+                        e[u] = i > j ? q : -q;
+                    }
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) mE = fmax(mE, __shfl_xor(mE, off));
+        if (lane == 0) red[wave] = mE;
+        __syncthreads();
+        mE = 0.0;
+        for (int w = 0; w < 16; ++w) mE = fmax(mE, red[w]);
+        const bool ok = mE <= VG_POLISH_EMAX;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = tid + u * 1024;
+            if (idx < mm) {
+                const int i = idx / m, j = idx - i * m;
+                const double ev = ok ? e[u] : 0.0;
+                J.E[idx] = ev;
+                J.R1[idx] = (i == j) ? 1.0 : ev;
+            }
+        }
+        return;
+    }
     // a wave takes whole rows (coalesced, no integer division); m <= 256: at most 4 column chunks and 16 rows per wave
     double ss = 0.0;
     for (int i = wave; i < m; i += 16)
@@ -1769,12 +1835,18 @@ hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st) 
         a.job[j] = jobs[j];
         if (jobs[j].m < 1 || jobs[j].m > 256) return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs), dim3(1024), 0, st, a);
+    size_t lds = 0;
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].m <= 128) lds = std::max(lds, (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double));
+    hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs), dim3(1024), lds, st, a);
     return hipGetLastError();
 }
 
 hipError_t vg_eigh_setup() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_rowqr_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_refine_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_rowqr_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),
