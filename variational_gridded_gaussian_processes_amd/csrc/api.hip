@@ -725,7 +725,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         if (refine) {
             VgRefineJob rj[2];
             for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, 0.0}; }
-            VG_HIP(vg_refine_launch(rj, 2, st));                                        // E -> U, I + E -> TH
+            VG_HIP(vg_refine_launch(rj, 2, st, ride ? &c->ride_proj : nullptr));        // E -> U, I + E -> TH   (+ rider: S = [B2;V2] Y)
+            if (ride) ride_stage = 1;
             VG_MARK(9);
             vg_gemm_init(&g);
             for (int k = 0; k < 2; ++k) {
@@ -770,10 +771,13 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         ej[k].sparse_first = (warm && subspace) ? 1 : 0;
     }
     // (counters were zeroed by the clear kernel at the start of the step)
-    VG_HIP(vg_eigh_launch(ej, 2, st, (ride && ride_stage == 0) ? &c->ride_proj : nullptr));
+    // riders of the main solve: whichever of the two projection launches is next (S when no earlier launch of the chain took
+    // it; [C;C1;C2] when the refinement launch carried S); what is still pending afterwards runs as a launch of its own
+    const VgGemmBatch* mr = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
+    VG_HIP(vg_eigh_launch(ej, 2, st, mr));
     VG_MARK(13);
-    if (ride && ride_stage == 0) ride_stage = 1;
-    if (ride && ride_stage == 1) VG_HIP(vg_gemm_launch(&c->ride_cc, st));      // no second host launch in this chain: by itself
+    if (mr) ++ride_stage;
+    if (ride && ride_stage == 1) { VG_HIP(vg_gemm_launch(&c->ride_cc, st)); ride_stage = 2; }
     c->ride_pending = false;
     if (from_slabs) VG_JOIN_WAIT(1);          // fused step: the projection branch (S, C slabs) ran beside the eigensolver chain
 

@@ -196,7 +196,7 @@ hipError_t vg_identity_launch(double* A, int m, hipStream_t st);
 // First-order refinement of a warm start (eigh.hip): from Gw = S G S^T, E_ij = g_ij / (g_ii - g_jj) for the elements above
 // the eigensolver's threshold; outputs E and R1 = I + E (both [m][m]); E = 0, R1 = I when some |E_ij| > 1e-3.
 struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol; };
-hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);
 hipError_t vg_eigh_setup();

@@ -1721,11 +1721,16 @@ hipError_t vg_identity_launch(double* A, int m, hipStream_t st) {
     return hipGetLastError();
 }
 
-struct VgRefineArgs { VgRefineJob job[2]; };
-__global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
+struct VgRefineArgs { VgRefineJob job[2]; int njobs; };
+__global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, const VgGemmBatch rider) {
     extern __shared__ double vr_dyn[];         // m <= 128: the packed lower triangle of Gw
     __shared__ double red[16];
     __shared__ double dg[256];
+    if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
+        if (threadIdx.x >= 512) return;
+        vg_gemm_body<64, 16, 512>(rider, vr_dyn, blockIdx.x - a.njobs);
+        return;
+    }
     const VgRefineJob& J = a.job[blockIdx.x];
     const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (m <= 128) {
@@ -1828,9 +1833,13 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a) {
         }
 }
 
-hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st) {
+hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider) {
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     VgRefineArgs a;
+    a.njobs = njobs;
+    VgGemmBatch rb;
+    rb.nprob = 0; rb.total_tiles = 0;
+    if (rider && rider->nprob > 0 && rider->total_tiles > 0) rb = *rider;
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
         if (jobs[j].m < 1 || jobs[j].m > 256) return hipErrorInvalidValue;
@@ -1838,7 +1847,8 @@ hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st) 
     size_t lds = 0;
     for (int j = 0; j < njobs; ++j)
         if (jobs[j].m <= 128) lds = std::max(lds, (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double));
-    hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs), dim3(1024), lds, st, a);
+    if (rb.total_tiles > 0) lds = std::max(lds, (size_t)(2 * VgTile<64, 16>::TILE * sizeof(double)));
+    hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs + rb.total_tiles), dim3(1024), lds, st, a, rb);
     return hipGetLastError();
 }
 
