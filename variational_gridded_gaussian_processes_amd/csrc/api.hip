@@ -177,9 +177,10 @@ static void layout(vggp_ctx* c, Bump& b) {
     c->rowpart = b.take<double>(m1 * 8);
     c->r1 = b.take<double>(m1);
     c->r1l = b.take<double>(m1);
-    c->r2 = b.take<double>(m2);
-    c->r2l = b.take<double>(m2);
-    c->dotpart = b.take<double>(64 * 4);
+    c->r2 = b.take<double>(2 * m2);          // [r2; r2l]: the two rows of one GEMM output
+    c->r2l = c->r2 + m2;
+    c->dotpart = b.take<double>(64 * 4);    // [4][64] per-tile partial sums (unused slots stay zero: the arena is cleared at plan time)
+    c->ol = b.take<double>(2 * m1);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         const long m = d.m, m2e = m + (m & 1);
@@ -196,10 +197,6 @@ static void layout(vggp_ctx* c, Bump& b) {
     c->beta = b.take<double>(m1 * m2);
     c->bl2 = b.take<double>(m1 * m2);
     c->bl1 = b.take<double>(m1 * m2);
-    c->X1 = b.take<double>(m1 * m1);
-    c->X1l = b.take<double>(m1 * m1);
-    c->X2 = b.take<double>(m2 * m2);
-    c->X2l = b.take<double>(m2 * m2);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         d.E = b.take<double>((long)d.m * d.m);
@@ -831,20 +828,28 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     VgMspace ms;
     ms.theta = c->theta; ms.lam1 = d1.lam0; ms.lam2 = d2.lam0; ms.P3 = c->P3;
     ms.E1 = d1.E; ms.F1 = d1.F; ms.E2 = d2.E; ms.F2 = d2.F;
-    ms.X1 = c->X1; ms.X1l = c->X1l; ms.X2 = c->X2; ms.X2l = c->X2l;
     ms.beta = c->beta; ms.bl2 = c->bl2; ms.bl1 = c->bl1; ms.invD = c->invD;
     ms.rowpart = c->rowpart; ms.r1 = c->r1; ms.r1l = c->r1l; ms.out = c->out;
-    ms.r2 = c->r2; ms.r2l = c->r2l; ms.dotpart = c->dotpart;
+    ms.r2 = c->r2; ms.r2l = c->r2l; ms.dotp = c->dotpart; ms.ol = c->ol;
     ms.m1 = (int)m1; ms.m2 = (int)m2; ms.n_total = (double)c->desc.n_total; ms.yy = yy_total;
     ms.ticket = c->ticket; ms.hout = c->d_hout;
     for (int k = 0; k < 2; ++k) { ms.jit[k] = c->d[k].jitter; ms.status[k] = c->d[k].status; ms.counters[k] = c->d[k].counters; }
     VG_HIP(vg_dstage_launch(&ms, st));
     VG_MARK(16);
     vg_gemm_init(&g);
-    vg_gemm_add(&g, c->beta, m2, 1, c->beta, 1, m2, c->X1, (int)m1, (int)m1, (int)m1, (int)m2);    // beta beta^T
-    vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, c->X1l, (int)m1, (int)m1, (int)m1, (int)m2);    // (beta lam2) beta^T
-    vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, c->X2, (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
-    vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, c->X2l, (int)m2, (int)m2, (int)m2, (int)m1);    // (lam1 beta)^T beta
+    // The four dot products of the gradient, sum(E1 o beta beta^T), sum(F1 o (beta lam2) beta^T), sum(E2 o beta^T beta),
+    // sum(F2 o (lam1 beta)^T beta), never materialise the m x m Gram matrices: sum_ij E_ij (beta beta^T)_ij = sum((E^T beta) o beta),
+    // so each is an m1 x m2 product whose tiles are multiplied by beta and summed in the GEMM's reduction epilogue (one word per
+    // tile, fixed order).  The column sums [r2; r2l] = [1; s1 lam1] (1/D) ride along as a 2-row product.
+    {
+        const int idot[4] = {
+            vg_gemm_add(&g, d1.E, 1, m1, c->beta, m2, 1, nullptr, (int)m2, (int)m1, (int)m2, (int)m1),     // E1^T beta
+            vg_gemm_add(&g, d1.F, 1, m1, c->bl2, m2, 1, nullptr, (int)m2, (int)m1, (int)m2, (int)m1),      // F1^T (beta lam2)
+            vg_gemm_add(&g, c->beta, m2, 1, d2.E, m2, 1, nullptr, (int)m2, (int)m1, (int)m2, (int)m2),     // beta E2
+            vg_gemm_add(&g, c->bl1, m2, 1, d2.F, m2, 1, nullptr, (int)m2, (int)m1, (int)m2, (int)m2)};     // (lam1 beta) F2
+        for (int q = 0; q < 4; ++q) { g.p[idot[q]].dotw = c->beta; g.p[idot[q]].dotw_ld = (int)m2; g.p[idot[q]].dot_out = c->dotpart + 64 * q; }
+        vg_gemm_add(&g, c->ol, m1, 1, c->invD, m2, 1, c->r2, (int)m2, 2, (int)m2, (int)m1);
+    }
     if (predict)
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];

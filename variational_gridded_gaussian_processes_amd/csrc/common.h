@@ -66,6 +66,11 @@ struct VgGemmP {
     int accum;
     int xcd_group;     // 1: XCD-aware block order (vg_gemm_xcd_group): the tile rows that stream the same B block share an XCD
     int tri;           // VG_TRI_*: one operand is triangular, tiles skip the k-range where it is zero (at 128-granularity)
+    // optional reduction epilogue: dot_out[tile] = sum over the tile of (alpha A B)_ij * dotw[i * dotw_ld + j] (fixed order:
+    // bitwise reproducible); C may then be null (nothing stored).  Not combined with split-K.
+    const double* dotw;
+    double* dot_out;
+    int dotw_ld;
 };
 #define VG_TRI_NONE 0
 #define VG_TRI_A_LOWER 1   // op(A)[i][k] = 0 for k > i:  k < roundup128(row0 + T)
@@ -219,10 +224,6 @@ struct VgMspace {
     const double* F1;        // [m1][m1]  Q1^T H0_1 Q1 (unsymmetrised, unit scale)
     const double* E2;
     const double* F2;
-    const double* X1;        // beta beta^T           [m1][m1]
-    const double* X1l;       // (beta lam2) beta^T    [m1][m1]
-    const double* X2;        // beta^T beta           [m2][m2]
-    const double* X2l;       // (beta lam1)^T beta    [m2][m2]
     // produced by dstage
     double* beta;            // [m1][m2]
     double* bl2;             // beta * lam2[None,:]
@@ -231,7 +232,9 @@ struct VgMspace {
     double* rowpart;         // [m1][8] per-row partial scalars
     double* r1;              // [m1] sum_i2 1/D
     double* r1l;             // [m1] sum_i2 lam2/D
-    double* r2;              // [m2] sum_i1 1/D        (vg_partial_kernel)
+    double* ol;              // [2][m1]: ones; s1 lam1   (left by the D-stage for the column-sum product [r2; r2l] = ol invD)
+    const double* dotp;      // [4][64] per-tile partial sums of the four dot products (reduction epilogue of the beta launch)
+    double* r2;              // [m2] sum_i1 1/D        (beta launch: row 0 of ol invD)
     double* r2l;             // [m2] sum_i1 lam1/D
     double* dotpart;         // [64][4] slices of sum(E1 o X1), sum(F1 o X1l), sum(E2 o X2), sum(F2 o X2l)
     // outputs

@@ -46,7 +46,7 @@ struct vggp_ctx {
     // cross-dimension buffers
     double *St = nullptr, *CCslab = nullptr, *payload = nullptr, *GH1 = nullptr;
     double *T3 = nullptr, *P3 = nullptr, *beta = nullptr, *bl2 = nullptr, *bl1 = nullptr, *invD = nullptr;
-    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *X1 = nullptr, *X1l = nullptr, *X2 = nullptr, *X2l = nullptr;
+    double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *ol = nullptr;
     double *out = nullptr, *theta = nullptr, *wq = nullptr;
     int st_split = 1, cc_split = 1;
     int gh_slabs[2] = {1, 1}, cc_slabs = 1;      // split-K slab counts actually produced by the last partials launch

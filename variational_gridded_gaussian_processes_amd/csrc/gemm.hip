@@ -74,6 +74,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     p.a_slab = 0;
     p.tri = VG_TRI_NONE;
     p.xcd_group = 0;
+    p.dotw = nullptr; p.dot_out = nullptr; p.dotw_ld = 0;
     p.tiles_m = (M + VG_BM - 1) / VG_BM;
     p.tiles_n = (N + VG_BN - 1) / VG_BN;
     p.tile_start = b->total_tiles;

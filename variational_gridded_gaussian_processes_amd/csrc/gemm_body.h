@@ -235,8 +235,10 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds, 
         }
     }
 
-    double* __restrict__ C = p.C + (long)ks * p.c_slab;
+    double* __restrict__ C = p.C ? p.C + (long)ks * p.c_slab : nullptr;
     const int ldc = p.ldc;
+    const double* __restrict__ dotw = p.dotw;
+    double dsum = 0.0;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -246,10 +248,24 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds, 
                 const int row = row0 + wr * WT + mb * 16 + fk + 4 * r;
                 const int col = col0 + wc * WTC + nb * 16 + fi;
                 if (row < M && col < N) {
-                    double* cp = C + (long)row * ldc + col;
                     const double v = p.alpha * acc[mb][nb][r];
-                    *cp = p.accum ? *cp + v : v;
+                    if (dotw) dsum += v * dotw[(long)row * p.dotw_ld + col];
+                    if (C) {
+                        double* cp = C + (long)row * ldc + col;
+                        *cp = p.accum ? *cp + v : v;
+                    }
                 }
             }
+    if (p.dot_out) {          // reduction epilogue: lanes -> wave (butterfly) -> workgroup (fixed order) -> one word per tile
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+        if (lane == 0) lds[wave] = dsum;            // (the k-loop ended with a barrier: the operand tiles are free)
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < NT / 64; ++w) tot += lds[w];
+            p.dot_out[bid - p.tile_start] = tot;
+        }
+    }
 }
 

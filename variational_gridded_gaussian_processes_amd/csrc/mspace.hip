@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void vg_dstage_kernel(const VgMspace ms) {
         for (int q = 0; q < 8; ++q) ms.rowpart[i1 * 8 + q] = acc[q];
         ms.r1[i1] = acc[8];
         ms.r1l[i1] = acc[9];
+        if (ms.ol) { ms.ol[i1] = 1.0; ms.ol[ms.m1 + i1] = l1; }      // left operand of the column-sum product [r2; r2l] = ol invD
     }
 }
 
@@ -104,57 +105,43 @@ hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---- final reduction: ONE launch ------------------------------------------------------------------------------------
-// VG_NPART workgroups compute the column sums of 1/D and lam1/D and slices of the four m x m dot products sum(E o X),
-// sum(F o Xl); the workgroup that draws the last ticket then does the O(m) combinations (all partial sums of all
-// workgroups are visible to it: release fence before the ticket, acquire after) and writes the 6 results plus the step's
-// diagnostics (jitter levels, status words, Jacobi counters) straight into the pinned host block.
-#define VG_NPART 64
+// ---- final reduction: ONE workgroup -----------------------------------------------------------------------------------
+// Everything the combination needs arrives reduced: the D-stage left the row sums, the beta launch (api.hip finish_enqueue,
+// step 9) the column sums [r2; r2l] = [1; s1 lam1] (1/D) and -- through the GEMM reduction epilogue -- the per-tile partial sums
+// of the four dot products sum(E o beta beta^T) = sum((E^T beta) o beta) etc.  One workgroup loads ~25 words per thread in a single
+// batch, sums them and writes the 6 results plus the step's diagnostics (jitter levels, status words, Jacobi counters) straight
+// into the pinned host block.  (Round 1 / early round 2: 64 workgroups formed the four m x m dot products and the column sums
+// here and met through a ticket; 17.6 us -- the ticket round trip and 1 MB of operands -- against ~7 now.)
 #define VG_NFIN 23          // scalars the final combination needs
+#define VG_NDOT 64          // slots per dot product in VgMspace::dotp (unused slots stay zero)
 
-// sums NV values per thread over the workgroup in one pass (wave shuffles, then one LDS stage); result in every thread
-// Inputs of the final combination that do not depend on this launch's partial sums: loaded by EVERY workgroup at kernel
-// start, together with its own operands (one memory round trip, ~2-4 us when the producer ran on another XCD), so that
-// the workgroup that turns out to be last only waits for the partials.
-struct VgFinPre { double S[VG_NFIN]; double e2, ff2; };
-__device__ __forceinline__ void vg_final_prefetch(const VgMspace& ms, VgFinPre& P) {
+// S[0..6]: row partials; [7..10]: dot products; [11],[12]: sum lam; [13..17]: dimension 1 sums; [18..22]: dimension 2
+__global__ __launch_bounds__(256) void vg_final_kernel(const VgMspace ms) {
+    __shared__ double red[4 * VG_NFIN];
+    __shared__ double stage[16];
     const int m1 = ms.m1, m2 = ms.m2, i = threadIdx.x;
-    const double s1 = ms.theta[2], s2 = ms.theta[3];
-    const bool o1 = i < m1, o2 = i < m2;
-    double rp[7];
+    const double s1 = ms.theta[2], s2 = ms.theta[3], v = ms.theta[4];
+    const double N = ms.n_total, yy = ms.yy;
+    const bool o1 = i < m1, o2 = i < m2, od = i < VG_NDOT;
+    // one batch of loads (m <= 256 = blockDim.x: one element per thread and array)
+    double rp[7], dpv[4];
 #pragma unroll
     for (int q = 0; q < 7; ++q) rp[q] = o1 ? ms.rowpart[i * 8 + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dpv[q] = od ? ms.dotp[q * VG_NDOT + i] : 0.0;
     const double la1 = o1 ? ms.lam1[i] : 0.0, e1 = o1 ? ms.E1[(long)i * m1 + i] : 0.0, f1 = o1 ? ms.F1[(long)i * m1 + i] : 0.0;
     const double r1 = o1 ? ms.r1[i] : 0.0, r1l = o1 ? ms.r1l[i] : 0.0;
     const double la2 = o2 ? ms.lam2[i] : 0.0, e2 = o2 ? ms.E2[(long)i * m2 + i] : 0.0, f2 = o2 ? ms.F2[(long)i * m2 + i] : 0.0;
+    const double r2 = o2 ? ms.r2[i] : 0.0, r2l = o2 ? ms.r2l[i] : 0.0;
+    double S[VG_NFIN];
 #pragma unroll
-    for (int q = 0; q < VG_NFIN; ++q) P.S[q] = 0.0;
+    for (int q = 0; q < 7; ++q) S[q] = rp[q];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) P.S[q] = rp[q];
-    P.S[11] = la1; P.S[12] = la2;
+    for (int q = 0; q < 4; ++q) S[7 + q] = dpv[q];
+    S[11] = la1; S[12] = la2;
     const double ff1 = 2.0 * s1 * f1, ff2 = 2.0 * s2 * f2;
-    P.S[13] = e1; P.S[14] = e1 * r1; P.S[15] = ff1 * r1l; P.S[16] = ff1; P.S[17] = e1 * s1 * la1;
-    P.S[18] = e2; P.S[21] = ff2; P.S[22] = e2 * s2 * la2;
-    P.e2 = e2; P.ff2 = ff2;
-}
-
-// S[0..6]: row partials; [7..10]: dot products; [11],[12]: sum lam; [13..17]: dimension 1 sums; [18..22]: dimension 2
-__device__ void vg_final_body(const VgMspace& ms, VgFinPre& P, double* red, double* stage /* 16 doubles, not aliased with red */) {
-    const int m1 = ms.m1, m2 = ms.m2;
-    const double s1 = ms.theta[2], s2 = ms.theta[3], v = ms.theta[4];
-    const double N = ms.n_total, yy = ms.yy;
-    double (&S)[VG_NFIN] = P.S;
-    {   // the partial sums of all workgroups (write-through stores there, cache-bypassing loads here)
-        const int i = threadIdx.x;
-        const bool o2 = i < m2, op = i < VG_NPART;
-        const double r2 = o2 ? vg_ld_agent(ms.r2 + i) : 0.0, r2l = o2 ? vg_ld_agent(ms.r2l + i) : 0.0;
-        double dpv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dpv[q] = op ? vg_ld_agent(ms.dotpart + i * 4 + q) : 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) S[7 + q] = dpv[q];
-        S[19] = P.e2 * r2; S[20] = P.ff2 * r2l;
-    }
+    S[13] = e1; S[14] = e1 * r1; S[15] = ff1 * r1l; S[16] = ff1; S[17] = e1 * s1 * la1;
+    S[18] = e2; S[19] = e2 * r2; S[20] = ff2 * r2l; S[21] = ff2; S[22] = e2 * s2 * la2;
     vg_block_sum_n<VG_NFIN>(S, red);
     if (threadIdx.x == 0) {
         // one thread, dependent f64 chain: reciprocals once, multiplications after (a software f64 division is ~30
@@ -190,8 +177,8 @@ __device__ void vg_final_body(const VgMspace& ms, VgFinPre& P, double* red, doub
         if (threadIdx.x >= 64 && threadIdx.x < 66) {
             // status word of the dimension: Cholesky status, else the eigensolver's replay-timeout flag (word 1)
             const int* sp = ms.status[threadIdx.x - 64];
-            const int s0 = sp ? sp[0] : 0, s1 = sp ? sp[1] : 0;
-            ired[8 + threadIdx.x - 64] = s0 ? s0 : (s1 ? VGGP_ENOCONV : 0);
+            const int s0 = sp ? sp[0] : 0, s1w = sp ? sp[1] : 0;
+            ired[8 + threadIdx.x - 64] = s0 ? s0 : (s1w ? VGGP_ENOCONV : 0);
         }
         if (threadIdx.x == 66) stage[15] = ms.theta[5];          // the step's sequence number travels back with the results
         __syncthreads();
@@ -200,91 +187,9 @@ __device__ void vg_final_body(const VgMspace& ms, VgFinPre& P, double* red, doub
     }
 }
 
-#ifdef VG_FIN_STAMP
-#define FS(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define FS(var)
-#endif
-__global__ __launch_bounds__(256) void vg_partial_kernel(const VgMspace ms) {
-    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
-    FS(f0);
-    __shared__ double red[4 * VG_NFIN];
-    __shared__ double stage[16];
-    __shared__ int s_last;
-    const int m1 = ms.m1, m2 = ms.m2, b = blockIdx.x;
-    const double s1 = ms.theta[2];
-    VgFinPre P;
-    vg_final_prefetch(ms, P);
-    // Every operand of this workgroup comes straight from the previous kernels (cold in this XCD's L2, ~2 us per
-    // dependent round trip), so all loads are issued before the first reduction: up to VG_PCOLS columns of 1/D per
-    // workgroup (column sums) and its slices of the four m x m dot products.
-    constexpr int VG_PCOLS = 4;                                   // columns b, b + 64, ... (m2 <= 256)
-    double v8[2 * VG_PCOLS + 4];
-#pragma unroll
-    for (int q = 0; q < 2 * VG_PCOLS + 4; ++q) v8[q] = 0.0;
-    // straight-line predicated loads (m <= 256 = blockDim.x, so one element per thread and column): a loop with a
-    // run-time trip count would make the compiler wait for each loop's loads before issuing the next loop's
-    {
-        const int i1 = threadIdx.x;
-        const bool rok = i1 < m1;
-        double iD[VG_PCOLS];
-        const double l1 = rok ? s1 * ms.lam1[i1] : 0.0;
-#pragma unroll
-        for (int cidx = 0; cidx < VG_PCOLS; ++cidx) {
-            const int i2 = b + cidx * VG_NPART;
-            iD[cidx] = (rok && i2 < m2) ? ms.invD[(long)i1 * m2 + i2] : 0.0;
-        }
-        double e1[4], x1[4], f1v[4], xl1[4], e2[4], x2[4], f2v[4], xl2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                             // m^2 / (64 * 256) <= 4 slices per thread
-            const long idx = (long)b * blockDim.x + threadIdx.x + (long)u * VG_NPART * blockDim.x;
-            const bool o1 = idx < (long)m1 * m1, o2 = idx < (long)m2 * m2;
-            e1[u] = o1 ? ms.E1[idx] : 0.0; x1[u] = o1 ? ms.X1[idx] : 0.0;
-            f1v[u] = o1 ? ms.F1[idx] : 0.0; xl1[u] = o1 ? ms.X1l[idx] : 0.0;
-            e2[u] = o2 ? ms.E2[idx] : 0.0; x2[u] = o2 ? ms.X2[idx] : 0.0;
-            f2v[u] = o2 ? ms.F2[idx] : 0.0; xl2[u] = o2 ? ms.X2l[idx] : 0.0;
-        }
-#pragma unroll
-        for (int cidx = 0; cidx < VG_PCOLS; ++cidx) { v8[2 * cidx] = iD[cidx]; v8[2 * cidx + 1] = l1 * iD[cidx]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            v8[2 * VG_PCOLS + 0] += e1[u] * x1[u];
-            v8[2 * VG_PCOLS + 1] += f1v[u] * xl1[u];
-            v8[2 * VG_PCOLS + 2] += e2[u] * x2[u];
-            v8[2 * VG_PCOLS + 3] += f2v[u] * xl2[u];
-        }
-    }
-    FS(f1);
-    vg_block_sum_n<2 * VG_PCOLS + 4>(v8, red);
-    FS(f2);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int cidx = 0; cidx < VG_PCOLS; ++cidx) {
-            const int i2 = b + cidx * VG_NPART;
-            if (i2 < m2) { vg_st_agent(ms.r2 + i2, v8[2 * cidx]); vg_st_agent(ms.r2l + i2, v8[2 * cidx + 1]); }
-        }
-    }
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) vg_st_agent(ms.dotpart + b * 4 + q, v8[2 * VG_PCOLS + q]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this workgroup's partial sums are at the memory side ...
-        const int t = __hip_atomic_fetch_add(ms.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the ticket
-        s_last = (t == VG_NPART - 1);
-    }
-    __syncthreads();
-    FS(f3);
-    if (!s_last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(ms.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
-    vg_final_body(ms, P, red, stage);
-#ifdef VG_FIN_STAMP
-    FS(f4);
-    if (threadIdx.x == 0) { ms.out[6] = (double)(f1 - f0) + 1e-6 * (double)(f2 - f1); ms.out[7] = (double)(f3 - f2) + 1e-6 * (double)(f4 - f3); }
-#endif
-}
-
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st) {
-    if (!ms->ticket) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(vg_partial_kernel, dim3(VG_NPART), dim3(256), 0, st, *ms);
+    if (!ms->dotp || !ms->r2 || !ms->r2l) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vg_final_kernel, dim3(1), dim3(256), 0, st, *ms);
     return hipGetLastError();
 }
 
