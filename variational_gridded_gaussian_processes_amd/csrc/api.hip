@@ -267,7 +267,8 @@ static void layout(vggp_ctx* c, Bump& b) {
     c->st_split = pick_split(st_tiles, (int)n2, ste ? atoi(ste) : 256);
     c->St = b.take<double>((size_t)c->st_split * 2 * m2 * n1);
     const int cc_tiles = (int)(((2 * m1 + 63) / 64) * ((m2 + 63) / 64));
-    c->cc_split = pick_split(cc_tiles, (int)n1, 64);
+    const char* cce = getenv("VGGP_CC_TARGET");
+    c->cc_split = pick_split(cc_tiles, (int)n1, cce ? atoi(cce) : 64);
     c->CCslab = b.take<double>((size_t)c->cc_split * 3 * m1 * m2);
 }
 

@@ -1617,17 +1617,24 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
     // Block Gram-Schmidt, 4 rows at a time (r is a multiple of 4): the block is projected off all finished rows twice
     // (4 k0 dot products per pass, 16 lanes each, one barrier; 512 threads subtract), then wave 0 alone orthonormalises the
     // four rows among themselves in registers (two elements per lane, wave reductions, no workgroup barrier).
+    // "Twice is enough", but only where it is needed (Kahan / Parlett): a projection is repeated when it removed more than
+    // half of a row's squared norm -- the trailing rows of Z, which are dominated by what leaks onto the leading eigenvectors;
+    // the leading rows of a warm start lose almost nothing and take one pass.  The norms come for free: |x|^2 rides in the same
+    // reduction as the dot products c_j, and |x - sum c_j q_j|^2 = |x|^2 - sum c_j^2 for orthonormal q_j.
     __shared__ double cb[4 * 64];
+    __shared__ double nb2[4];
+    __shared__ int need2[4];
     const int grp = tid >> 4, l16 = lane & 15;               // 64 groups of 16 lanes
     for (int k0 = 0; k0 < r; k0 += 4) {
         double* vb = V + k0 * m;
         for (int pass = 0; pass < 2 && k0 > 0; ++pass) {
-            for (int p = grp; p < 4 * k0; p += 64) {
+            for (int p = grp; p < 4 * k0 + (pass == 0 ? 4 : 0); p += 64) {
                 const int bb = p & 3, j = p >> 2;
+                const double* vj = j < k0 ? V + j * m : vb + bb * m;        // j == k0: the row's own squared norm
                 double s = 0.0;
-                for (int e = l16; e < m; e += 16) s += V[j * m + e] * vb[bb * m + e];
+                for (int e = l16; e < m; e += 16) s += vj[e] * vb[bb * m + e];
                 s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-                if (l16 == 0) cb[bb * 64 + j] = s;
+                if (l16 == 0) { if (j < k0) cb[bb * 64 + j] = s; else nb2[bb] = s; }
             }
             __syncthreads();
             if (tid < 512) {
@@ -1645,8 +1652,15 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
                     for (; j < k0; ++j) x0 += cc[j] * V[j * m + e];
                     vb[bb * m + e] -= (x0 + x1) + (x2 + x3);
                 }
+            } else if (pass == 0 && tid >= 512 && tid < 516) {          // one lane per row decides about the second pass
+                const int bb = tid - 512;
+                const double* cc = cb + bb * 64;
+                double sc2 = 0.0;
+                for (int j = 0; j < k0; ++j) sc2 += cc[j] * cc[j];
+                need2[bb] = !(nb2[bb] - sc2 >= 0.5 * nb2[bb]);              // (also for NaN)
             }
             __syncthreads();
+            if (pass == 0 && !(need2[0] | need2[1] | need2[2] | need2[3])) break;      // uniform
         }
         if (wave == 0) {
             double x[4][2];
@@ -1657,24 +1671,30 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
             }
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
-#pragma unroll
+                double n2 = 0.0;
                 for (int pass = 0; pass < 2; ++pass) {
-                    double c[3] = {0.0, 0.0, 0.0};             // classical order: the (up to three) reductions are independent
+                    // the (up to three) dot products with the block's finished rows and the row's own squared norm: four
+                    // independent reductions through one butterfly
+                    double c[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int jb = 0; jb < bb; ++jb) c[jb] = x[bb][0] * x[jb][0] + x[bb][1] * x[jb][1];
+                    c[3] = x[bb][0] * x[bb][0] + x[bb][1] * x[bb][1];
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-                        for (int jb = 0; jb < bb; ++jb) c[jb] += __shfl_xor(c[jb], off);
+                        for (int jb = 0; jb < 4; ++jb)
+                            if (jb < bb || jb == 3) c[jb] += __shfl_xor(c[jb], off);
                     }
+                    double sc2 = 0.0;
 #pragma unroll
                     for (int jb = 0; jb < bb; ++jb) {
                         x[bb][0] -= c[jb] * x[jb][0];
                         x[bb][1] -= c[jb] * x[jb][1];
+                        sc2 += c[jb] * c[jb];
                     }
+                    n2 = c[3] - sc2;                                         // |x|^2 after the projection
+                    if (n2 >= 0.5 * c[3]) break;                             // wave-uniform: little was removed, once is enough
                 }
-                double n2 = x[bb][0] * x[bb][0] + x[bb][1] * x[bb][1];
-                for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
                 const double sc = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
                 x[bb][0] *= sc; x[bb][1] *= sc;
             }
