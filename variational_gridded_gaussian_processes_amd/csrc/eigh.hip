@@ -508,7 +508,13 @@ __device__ __forceinline__ bool vg_newton_diag(int m, const double* Wpk, double*
             __syncthreads();
         }
         double* WR = (R == T) ? E : T;                                         // the free buffer
-        vg_nt_mm<0>(WR, Wn, ld, 1, R, mp, ld);                                 // W R
+        if (it == 0) WR = R;                                                   // W = I: W R is R itself
+        else vg_nt_mm<0>(WR, Wn, ld, 1, R, mp, ld);                            // W R
+        if (!f3) {
+            // every |E_ij| <= 1e-8: what W <- W (I + E) leaves off the diagonal is O(|E|^2 ||H||) <= 1e-16 ||H||, far below any
+            // threshold, and the diagonal moves at second order too -- no need to form W^T H0 W again or to look at it
+            iters = it + 1; *Hout = H; *Wout = WR; return true;
+        }
         double* Wnew = WR;
         if (f2) {
             double* S = (WR == E) ? T : E;
