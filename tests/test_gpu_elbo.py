@@ -475,3 +475,45 @@ def test_readouts_after_warm_rbf_steps_have_cold_accuracy(engine):
             pm, pv = engine.posterior(torch.tensor(xs, device=DEV))
             om, ov = Kr.posterior(ref, f1, f2, xs)
             assert rel(pm.cpu().numpy(), om) < 1e-6 and rel(pv.cpu().numpy(), ov) < 1e-5
+
+
+def _rbf_trajectory(engine, profile, steps=26):
+    """A smooth 1 %-per-step path with one 30 % jump: subspace start, Newton Ritz solve, riders -- and their fall-backs."""
+    n, m = 192, 64
+    X, y, x1, x2 = D.gen_grid(n, n)
+    g = np.linspace(0, 1, m)
+    engine.plan("rbf", "points", g, x1, "rbf", "points", g, x2, warm_start=True)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    yy = engine.sumsq(Y)
+    engine.profile(profile)
+    out = []
+    th0 = np.array([0.2, 0.22, 1.0, 1.1, 0.01])
+    for k in range(steps):
+        th = th0 * (1 + 0.01 * k) * (1.3 if k >= 15 else 1.0)
+        elbo, grad, info = engine.elbo_step(Y, yy, th)
+        out.append((th, elbo, grad.copy(), info))
+    engine.profile(False)
+    return out, (y.reshape(n, n), Kr.Factor("points", "rbf", g, x1), Kr.Factor("points", "rbf", g, x2))
+
+
+def test_rbf_warm_chain_with_jump_vs_oracle(engine):
+    """The RBF fit-loop chain (subspace start -> row QR -> Newton iteration on the Ritz matrix -> sparse-first main solve, the
+    projection launches riding in the chain's single-workgroup launches) against the structured oracle along a path that
+    contains a jump the warm start cannot follow smoothly."""
+    out, (Yn, f1, f2) = _rbf_trajectory(engine, profile=False)
+    for k in (0, 1, 2, 5, 14, 15, 16, 17, 25):
+        th, elbo, grad, info = out[k]
+        ref = Kr.elbo_step(Yn, f1, f2, th)
+        assert abs(elbo - ref.elbo) <= 1e-9 * abs(ref.elbo), (k, info)
+        assert rel(grad, ref.grad) < RTOL, (k, info)
+    assert all(o[3]["status"] == 0 for o in out)
+
+
+def test_riders_and_graph_equal_plain_launches(engine):
+    """Profiling mode runs every launch group by itself on one stream (no graph replay, no riders): the same trajectory must
+    give the same numbers as the default mode, to rounding of the reduction orders that differ (none should)."""
+    a, _ = _rbf_trajectory(engine, profile=False, steps=20)
+    b, _ = _rbf_trajectory(engine, profile=True, steps=20)
+    for k, (ra, rb) in enumerate(zip(a, b)):
+        assert abs(ra[1] - rb[1]) <= 1e-11 * abs(rb[1]), k
+        assert rel(ra[2], rb[2]) < 1e-9, k

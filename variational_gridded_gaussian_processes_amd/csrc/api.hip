@@ -767,6 +767,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         ej[k].err = d.status + 1;      // replay timeout flag (folded into the step status by the final kernel)
         ej[k].polish0 = (warm && refine) ? 1 : 0;
         ej[k].sparse_first = (warm && subspace) ? 1 : 0;
+        ej[k].null_from = (warm && subspace) ? d.sub_r : 0;
     }
     // (counters were zeroed by the clear kernel at the start of the step)
     // riders of the main solve: whichever of the two projection launches is next (S when no earlier launch of the chain took
@@ -999,6 +1000,7 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
         c->have_step = false;
     }
+    if (status == VG_ESUBMISS) { c->sub_next = false; return VG_ESUBMISS; }      // (the caller repeats the step; the warm start was reset above)
     if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
     if (status == VGGP_ENOCONV) { vg_set_error("Jacobi eigensolver did not converge"); return VGGP_ENOCONV; }
     for (int k = 0; k < 2; ++k) {
@@ -1036,8 +1038,18 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     return VGGP_OK;
 }
 
+static int elbo_finish_once(vggp_ctx* c, const double* payload, double yy_total, const double theta[5],
+                            double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_total, const double theta[5],
                                 double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
+    int rc = elbo_finish_once(c, payload, yy_total, theta, elbo_out, grad_out, info, stream);
+    if (rc == VG_ESUBMISS) rc = elbo_finish_once(c, payload, yy_total, theta, elbo_out, grad_out, info, stream);   // cold, same payload
+    if (rc == VG_ESUBMISS) { vg_set_error("the eigensolver chain failed twice on the same step"); rc = VGGP_ENOCONV; }
+    return rc;
+}
+
+static int elbo_finish_once(vggp_ctx* c, const double* payload, double yy_total, const double theta[5],
+                            double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned || !c->have_partials) { vg_set_error("vggp_elbo_finish: call vggp_elbo_partials first"); return VGGP_ESTATE; }
     VG_REQUIRE(payload && theta && elbo_out && grad_out, "vggp_elbo_finish: null argument");
     VG_ENTER_DEVICE(c->device);
@@ -1057,8 +1069,27 @@ extern "C" int vggp_elbo_finish(vggp_ctx* c, const double* payload, double yy_to
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
 
+static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
+                          double grad_out[5], vggp_info* info, void* stream);
+// A step whose subspace start turns out to have missed part of the range (VG_ESUBMISS: the hyper-parameters jumped) is repeated
+// once, cold -- the failed attempt has already reset the warm start.  A jump the host can see beforehand (> 5 % in a lengthscale
+// since the last step; the Gram matrices depend on nothing else) skips the attempt.
 extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
                               double grad_out[5], vggp_info* info, void* stream) {
+    if (c && c->planned && theta) {
+        bool jump = false;
+        for (int k = 0; k < 2; ++k) jump = jump || (c->last_ell[k] > 0.0 && std::fabs(theta[k] / c->last_ell[k] - 1.0) > 0.05);
+        if (jump && c->sub_next) { c->warm_run = 0; for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false; }
+        c->last_ell[0] = theta[0]; c->last_ell[1] = theta[1];
+    }
+    int rc = elbo_step_once(c, Y, yy_total, theta, elbo_out, grad_out, info, stream);
+    if (rc == VG_ESUBMISS) rc = elbo_step_once(c, Y, yy_total, theta, elbo_out, grad_out, info, stream);
+    if (rc == VG_ESUBMISS) { vg_set_error("the eigensolver chain failed twice on the same step"); rc = VGGP_ENOCONV; }
+    return rc;
+}
+
+static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
+                          double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(Y && theta && elbo_out && grad_out, "vggp_elbo_step: null argument");
     VG_ENTER_DEVICE(c->device);

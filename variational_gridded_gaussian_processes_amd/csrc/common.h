@@ -187,6 +187,7 @@ struct VgEigJob {
     const double* Hl = nullptr;  // the matrix as a product G = Hl Hr^T (m x hk row-major factors; LDS variant only): formed by the
     const double* Hr = nullptr;  // producer workgroup itself on the matrix cores; `G` is then ignored
     int hk = 0;
+    int null_from = 0;     // subspace start: rows >= null_from of G must be numerically null (else bit 1 of *err is raised)
     int newton = 0;        // nearly diagonal small problem (m <= 48, no start basis): try the Newton start first (vg_newton_diag)
     int sparse_first = 0;  // skip the dense phase: the start basis already block-diagonalises G (subspace start), a few elements remain
 };
@@ -207,6 +208,8 @@ hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const
 hipError_t vg_eigh_setup();
 
 // ---- m-space elementwise / reductions (mspace.hip) -----------------------------
+#define VG_ESUBMISS (-100)   // internal status: the subspace start of the eigensolver chain missed part of the range (never returned
+                            // to the caller: vggp_elbo_step / vggp_elbo_finish repeat the step with a cold start)
 struct VgHostOut {          // pinned readback block (one 128-byte burst)
     double out[8];
     double jitter[2];

@@ -81,6 +81,7 @@ struct vggp_ctx {
     double last_yy = 0.0;
     VgGemmBatch ride_proj, ride_cc;   // the projection launches of a fused warm step, deferred to the eigensolver chain as riders
     bool ride_pending = false;
+    double last_ell[2] = {0.0, 0.0};  // lengthscales of the previous step (jump detection, vggp_elbo_step)
     bool pred_consumed = false;       // this prediction's Newton-Schulz step has been applied to Fp (it accumulates: once only)
     bool refine_next = false;
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start

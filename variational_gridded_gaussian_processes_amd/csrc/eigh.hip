@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #define VG_EIG_TOL 1e-13         // default relative off-diagonal threshold (VgEigJob::tol)
+#define VG_SUB_MISS 1e-12        // subspace start: largest admissible Rayleigh quotient of a complement row, relative to lam_max
 #define VG_EIG_TOL_SUB 1e-12     // ... of a sparse_first job (see vg_jacobi_body)
 #ifndef VG_BJ_MAX_M
 #define VG_BJ_MAX_M 128            // block Jacobi up to this size, scalar cyclic Jacobi beyond
@@ -552,7 +553,7 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
     RT(0);
     // load the lower triangle (zero padded) and the Frobenius norm
     // (a wave takes whole rows -- coalesced, no integer division -- and four rows' loads are in flight together)
-    double ss = 0.0;
+    double ss = 0.0, dmax = 0.0, nmax = 0.0;       // (dmax, nmax: largest diagonal element / largest one from row null_from on)
     if (INLDS && J.Hl && J.Hr) {
         // the matrix is given as a product: G = Hl Hr^T (m x hk factors, row-major; the Ritz matrix H = (V1 G) V1^T of the
         // subspace start) -- one 16 x 16 block of the lower triangle per wave on the matrix cores, operands straight from global
@@ -643,6 +644,7 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
                 if (i < m2 && j <= i) {
                     W[vg_tri(i) + j] = v[u][h];
                     ss += (i == j) ? v[u][h] * v[u][h] : 2.0 * v[u][h] * v[u][h];
+                    if (i == j) { dmax = fmax(dmax, v[u][h]); if (i >= J.null_from) nmax = fmax(nmax, fabs(v[u][h])); }
                 }
             }
         }
@@ -673,13 +675,27 @@ __device__ __forceinline__ void vg_jacobi_body(const VgEigJob& J, double* W, dou
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        dmax = fmax(dmax, __shfl_xor(dmax, off));
+        nmax = fmax(nmax, __shfl_xor(nmax, off));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = ss; red[16 + (tid >> 6)] = dmax; red[32 + (tid >> 6)] = nmax; }
     if (tid == 0) { nact_s[0] = 0; nact_s[1] = 0; }
     if (!INLDS) __threadfence_block();
     __syncthreads();
     double fro = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) fro += red[w];
+    // Subspace start: the rows from null_from on are the previous complement projected off the new range; they must be
+    // numerically null for the new matrix too.  After a jump of the hyper-parameters (measured: > 5 % in a lengthscale) they are
+    // not -- the range has moved out of the predicted subspace -- and since those rows were never re-orthonormalised the result
+    // would be silently wrong.  The complement's Rayleigh quotients tell: 1e-16 lam_max on a valid start, 3e-10 at a 6 % jump.
+    // The flag makes the host repeat the step cold (api.hip: VG_ESUBMISS).
+    if (J.null_from > 0 && J.null_from < m && tid == 0) {
+        double dm = 0.0, nm = 0.0;
+        for (int w = 0; w < (nthr >> 6); ++w) { dm = fmax(dm, red[16 + w]); nm = fmax(nm, red[32 + w]); }
+        if (!(nm <= VG_SUB_MISS * dm) && J.err) atomicOr(J.err, 2);
+    }
     // sparse_first (subspace start): G arrives as E G E^T through two GEMMs, i.e. with rounding noise of ~sqrt(m) eps ||G||
     // in every element (measured at 1024^2 RBF, m = 128: 20 elements of the range block at 1-5x the default threshold, nothing
     // else above it; tools/dbg_gw.py) -- the default threshold sits below that floor and the solver then spends 15-20 rounds
@@ -1566,7 +1582,7 @@ __global__ __launch_bounds__(1024) void vg_eigh_kernel(const VgEigArgs a, const 
     __shared__ VgActRec actrec[128];          // rotating pairs of the current round (half <= 128)
     __shared__ unsigned char isact[512];
     __shared__ int nact_s[2];
-    __shared__ double red[16];
+    __shared__ double red[48];
     const int bid = blockIdx.x;
     if (bid >= a.neig) {          // rider role: one 64 x 64 tile of the attached GEMM batch, 8 waves (the other 8 leave)
         if (threadIdx.x >= 512) return;

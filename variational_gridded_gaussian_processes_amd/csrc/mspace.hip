@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void vg_final_kernel(const VgMspace ms) {
             // status word of the dimension: Cholesky status, else the eigensolver's replay-timeout flag (word 1)
             const int* sp = ms.status[threadIdx.x - 64];
             const int s0 = sp ? sp[0] : 0, s1w = sp ? sp[1] : 0;
-            ired[8 + threadIdx.x - 64] = s0 ? s0 : (s1w ? VGGP_ENOCONV : 0);
+            // (word 1: bit 0 = replay timeout, bit 1 = the subspace start missed part of the range -> the host repeats the step)
+            ired[8 + threadIdx.x - 64] = s0 ? s0 : ((s1w & 1) ? VGGP_ENOCONV : ((s1w & 2) ? VG_ESUBMISS : 0));
         }
         if (threadIdx.x == 66) stage[15] = ms.theta[5];          // the step's sequence number travels back with the results
         __syncthreads();
