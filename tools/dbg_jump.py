@@ -9,19 +9,21 @@ n, m = 192, 64
 X, y, x1, x2 = D.gen_grid(n, n)
 g = np.linspace(0, 1, m)
 e = Engine(0)
-e.plan("rbf", "points", g, x1, "rbf", "points", g, x2, warm_start=True)
+kind = sys.argv[2] if len(sys.argv) > 2 else "rbf"
+e.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=True)
 Y = torch.tensor(y.reshape(n, n), device="cuda")
 yy = e.sumsq(Y)
-f1, f2 = Kr.Factor("points", "rbf", g, x1), Kr.Factor("points", "rbf", g, x2)
+f1, f2 = Kr.Factor("points", kind, g, x1), Kr.Factor("points", kind, g, x2)
 th0 = np.array([0.2, 0.22, 1.0, 1.1, 0.01])
 jump = float(sys.argv[1]) if len(sys.argv) > 1 else 1.3
+kind = sys.argv[2] if len(sys.argv) > 2 else "rbf"
 for k in range(20):
     th = th0 * (1 + 0.01 * k) * (jump if k >= 15 else 1.0)
     elbo, grad, info = e.elbo_step(Y, yy, th)
     if k >= 13:
         ref = Kr.elbo_step(y.reshape(n, n), f1, f2, th)
         print(k, "rel err elbo %.2e grad %.2e" % (abs(elbo - ref.elbo) / abs(ref.elbo), np.abs(grad - ref.grad).max() / np.abs(ref.grad).max()), info["rounds"], info["sweeps"], info["status"])
-    if k == 15:
+    if k == 15 and kind == 'rbf' and len(sys.argv) > 3:
         import ctypes as C
         e.lib.vggp_debug_read_gwork.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64]
         for dim in (0, 1):
