@@ -504,7 +504,9 @@ def test_rbf_warm_chain_with_jump_vs_oracle(engine):
     for k in (0, 1, 2, 5, 14, 15, 16, 17, 25):
         th, elbo, grad, info = out[k]
         ref = Kr.elbo_step(Yn, f1, f2, th)
-        assert abs(elbo - ref.elbo) <= 1e-9 * abs(ref.elbo), (k, info)
+        # (1e-8: after the jump the lengthscales are 0.3 -- cond(K + 1e-8 I) ~ 1e10 -- and GPU and numpy Cholesky differ by
+        #  their rounding; measured 6e-10 ... 2.3e-9 depending on the elimination order of the 16 x 16 blocks)
+        assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, info)
         assert rel(grad, ref.grad) < RTOL, (k, info)
     assert all(o[3]["status"] == 0 for o in out)
 
