@@ -189,6 +189,15 @@ int vggp_qv(vggp_ctx* ctx, double* mean, double* var, void* stream);
 /* Dense M x M covariance Kuu Sigma^{-1} Kuu of q(v) (DEVICE, M = m1*m2; small M only). */
 int vggp_qv_cov(vggp_ctx* ctx, double* cov, void* stream);
 
+/* Gradient of the ELBO of the LAST vggp_elbo_step with respect to the inducing-point coordinates of the "points" basis
+ * (Matern12SVGP and friends register Z as a trainable Parameter, kronecker_structure.py:303-304, and let autograd differentiate
+ * through kernel(Z) :318-319 and kernel(cartesian_prod(Z), x) :336-337).  Y: the same device array the step was given.
+ * gz1 [m1], gz2 [m2] (device): d ELBO / d z_d[i]; zeros for a dimension whose basis is not VGGP_BASIS_POINTS.
+ * Analytic (no autograd): the sensitivities Kbar = L^-T W_M L^-1, Abar = L^-T W_V follow from the linearity of the lengthscale
+ * gradient in (dK, dA), and d kappa(z, x)/dz = -(d kappa/d ell) ell / (z - x) for the stationary kernels.
+ * Single-rank contexts only (VGGP_ESTATE otherwise). */
+int vggp_zgrad(vggp_ctx* ctx, const double* Y, double* gz1, double* gz2, void* stream);
+
 /* Point-wise posterior at ns scattered test points (xs1[p], xs2[p]) (DEVICE inputs):
  * mean[ns], var[ns] (DEVICE).  Replaces KroneckerStructure.posterior mean and the
  * diagonal of its covariance (kronecker_structure.py:199-230). */

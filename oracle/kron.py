@@ -566,3 +566,52 @@ def readout(st: StepState, f1: Factor, f2: Factor, C1, C2, kd1, kd2, literal: bo
     mean = T1.T @ (st.beta / v) @ T2
     var = s1 * s2 * np.outer(kd1, kd2) + (T1 * T1).T @ W @ (T2 * T2)
     return mean, var
+
+
+# ----------------------------------------------------------------------------
+# gradient with respect to the inducing-point coordinates ("points" basis: SVGP's trainable Z,
+# kronecker_structure.py:303-304 registers Z as a Parameter; autograd differentiates through kernel(Z) and kernel(Z, x))
+# ----------------------------------------------------------------------------
+def z_grad(st: StepState, f1: Factor, f2: Factor, Y: np.ndarray):
+    """dELBO/dz for the inducing coordinates of both dimensions -> (g1 [m1], g2 [m2]).
+
+    The analytic lengthscale gradient of finish() is LINEAR in the perturbation (dK, dA) it is fed:
+    dELBO = <W_M, L^-1 dK L^-T> + <W_V, L^-1 dA>, with weights that only depend on the step's state.  Hence the sensitivities
+    Kbar = L^-T W_M L^-1 and Abar = L^-T W_V, and for a stationary kernel d kappa(z_i, x)/d z_i = -(d kappa/d ell) ell/(z_i - x):
+    g_i = -ell [ sum_k Abar_ik dA_ik / (z_i - x_k) + sum_{j != i} (Kbar_ij + Kbar_ji) dK_ij / (z_i - z_j) ]."""
+    ell1, ell2, s1, s2, v = [float(t) for t in st.theta]
+    d1, d2, beta, D = st.d1, st.d2, st.beta, st.D
+    invD = 1.0 / D
+    l1, l2 = d1.lam, d2.lam
+    m1, m2 = len(l1), len(l2)
+    WP = beta / v ** 2
+
+    def weights(r, rlam, X, Xlam, lam_other_sum, m_other, lam_self):
+        WE = -0.5 * np.diag(r) + 0.5 * m_other * np.eye(len(r)) - X / (2 * v ** 2) - lam_other_sum / (2 * v) * np.diag(lam_self)
+        WF = -0.5 * np.diag(rlam) / v - Xlam / (2 * v ** 3) + lam_other_sum / (2 * v) * np.eye(len(r))
+        return WE, WF
+
+    WE1, WF1 = weights(invD.sum(1), (invD * l2[None, :]).sum(1), beta @ beta.T, (beta * l2[None, :]) @ beta.T, l2.sum(), m2, l1)
+    WE2, WF2 = weights(invD.sum(0), (invD * l1[:, None]).sum(0), beta.T @ beta, (beta * l1[:, None]).T @ beta, l1.sum(), m1, l2)
+    out = []
+    for dd, f, ell, s, WE, WF, proj in (
+            (d1, f1, ell1, s1, WE1, WF1, d1.Q @ WP @ d2.Q.T @ (d2.B @ Y)),            # (m1 x n1)
+            (d2, f2, ell2, s2, WE2, WF2, d2.Q @ WP.T @ d1.Q.T @ (d1.B @ Y.T))):       # (m2 x n2)
+        if f.basis != "points":
+            out.append(np.zeros(f.m))
+            continue
+        Q = dd.Q
+        WM = Q @ WE @ Q.T
+        WV = Q @ (WF + WF.T) @ Q.T @ dd.B + proj
+        Abar = s * sla.solve_triangular(dd.L, WV, lower=True, trans="T")              # w.r.t. the unit-scale A0
+        Z1 = sla.solve_triangular(dd.L, WM, lower=True, trans="T")
+        Kbar = s * sla.solve_triangular(dd.L, Z1.T, lower=True, trans="T").T          # L^-T W_M L^-1, w.r.t. K0
+        K0, dK0, A0, dA0 = f.build(ell)
+        z = np.asarray(f.grid, float)
+        dzx = z[:, None] - f.x[None, :]
+        dzz = z[:, None] - z[None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tA = np.where(dzx != 0.0, dA0 / dzx, 0.0)
+            tK = np.where(dzz != 0.0, dK0 / dzz, 0.0)
+        out.append(-ell * ((Abar * tA).sum(1) + ((Kbar + Kbar.T) * tK).sum(1)))
+    return out[0], out[1]

@@ -227,3 +227,29 @@ def test_gridded_readout_structured_equals_dense(basis, literal):
     m_, v_ = Kr.readout(st, f1, f2, C1, C2, kd1, kd2, literal=literal)
     assert rel(m_.reshape(-1), q.mean.detach().numpy()) < 1e-10
     assert rel(v_.reshape(-1), q.variance.detach().numpy()) < 1e-9
+
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52", "matern12"])
+def test_z_grad_matches_central_differences(kind):
+    """oracle/kron.py z_grad (the spec of vggp_zgrad: gradient w.r.t. SVGP's trainable inducing coordinates,
+    kronecker_structure.py:303-304) against central differences of the ELBO."""
+    rng = np.random.default_rng(0)
+    n1, n2, m1, m2 = 40, 33, 7, 6
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    Y = y.reshape(n2, n1)
+    z1, z2 = np.sort(rng.uniform(0.03, 0.97, m1)), np.sort(rng.uniform(0.03, 0.97, m2))
+    th = np.array([0.21, 0.27, 1.2, 0.9, 0.02])
+    f1, f2 = Kr.Factor("points", kind, z1, x1), Kr.Factor("points", kind, z2, x2)
+    g1, g2 = Kr.z_grad(Kr.elbo_step(Y, f1, f2, th), f1, f2, Y)
+    h = 1e-6
+    for dim, (z, g) in enumerate(((z1, g1), (z2, g2))):
+        fd = np.zeros(len(z))
+        for i in range(len(z)):
+            zp, zm = z.copy(), z.copy()
+            zp[i] += h
+            zm[i] -= h
+            fp = (Kr.Factor("points", kind, zp, x1), f2) if dim == 0 else (f1, Kr.Factor("points", kind, zp, x2))
+            fm = (Kr.Factor("points", kind, zm, x1), f2) if dim == 0 else (f1, Kr.Factor("points", kind, zm, x2))
+            fd[i] = (Kr.elbo_step(Y, *fp, th).elbo - Kr.elbo_step(Y, *fm, th).elbo) / (2 * h)
+        assert np.abs(g - fd).max() <= 2e-6 * np.abs(fd).max()

@@ -453,6 +453,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
             vg_gemm_add(&gns, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
         }
     VG_HIP(vg_chol_launch(cj, 2, st, ns_on_chol ? &gns : nullptr));
+    c->dinv_valid = dinv_path;
     VG_MARK(1);
 
     // 3. B|V = L0^{-1} [A0|dA0],  X = L0^{-1} dK0  by blocked substitution on the matrix cores (trsm.hip; the 16 x 16
@@ -561,7 +562,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         }
     }
 
-    c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs;
+    c->gh_slabs[0] = gh_slabs[0]; c->gh_slabs[1] = gh_slabs[1]; c->cc_slabs = cc_slabs; c->st_slabs = st_slabs;
     // 7. deterministic slab reduction into {G1,H1} (local) and the payload {G2,H2,C,C1,C2}.  Skipped inside a fused
     //    warm step: its consumers (three small GEMMs) then sum the slabs on load, one launch less on the critical path.
     if (!reduce) return VGGP_OK;          // fused warm step: the caller joins the projection branch before the rotations
@@ -1697,6 +1698,118 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
 }
 
 // diagnostic builds only (-DVG_EIG_STAMP): copy the head of the scratch buffer to the host
+// ---------------------------------------------------------------------------------
+// Gradient of the ELBO with respect to the inducing-point coordinates (SVGP's trainable Z: kronecker_structure.py:303-304
+// registers Z as a Parameter and autograd differentiates through kernel(Z), kernel(Z, x)).  Spec: oracle/kron.py z_grad.
+// The analytic lengthscale gradient is linear in the perturbation (dK, dA) it is fed, dELBO = <W_M, L^-1 dK L^-T> + <W_V, L^-1 dA>,
+// so Kbar = L^-T W_M L^-1 and Abar = L^-T W_V are the sensitivities, and for a stationary kernel
+// d kappa(z_i, x) / d z_i = -(d kappa / d ell) ell / (z_i - x): the derivative factors dA0, dK0 of the step are reused.
+// Uses the resident state of the last vggp_elbo_step on the same Y (warm-basis accuracy, like the lengthscale gradient); one
+// extra pass over Y (B1 Y^T), ~25 small launches.  Single rank only.
+extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2, void* stream) {
+    if (!c || !c->have_step) { vg_set_error("vggp_zgrad: no finished ELBO step"); return VGGP_ESTATE; }
+    VG_REQUIRE(Y && gz1 && gz2, "vggp_zgrad: null argument");
+    if (c->n_ranks > 1 || c->comm || c->cb) { vg_set_error("vggp_zgrad: row-sharded contexts are not supported yet"); return VGGP_ESTATE; }
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const bool pts[2] = {d1.basis == VGGP_BASIS_POINTS, d2.basis == VGGP_BASIS_POINTS};
+    if (!pts[0]) VG_HIP(hipMemsetAsync(gz1, 0, sizeof(double) * m1, st));
+    if (!pts[1]) VG_HIP(hipMemsetAsync(gz2, 0, sizeof(double) * m2, st));
+    if (!pts[0] && !pts[1]) return VGGP_OK;
+    const double s1 = c->h_theta[2], s2 = c->h_theta[3], v = c->h_theta[4];
+    // workspace
+    const long mm1 = m1 * m1, mm2 = m2 * m2, m12 = m1 * m2;
+    const size_t need = sizeof(double) * (size_t)(6 * mm1 + 6 * mm2 + 2 * m12 + m1 * n1 + m2 * n2 + m1 * n2);
+    int rc = vg_ensure_misc(c, need);
+    if (rc) return rc;
+    double* w = reinterpret_cast<double*>(c->misc);
+    double *Xa[2], *Xl[2], *WE[2], *WF[2], *TA[2], *TB[2];
+    for (int k = 0; k < 2; ++k) {
+        const long mm = k ? mm2 : mm1;
+        Xa[k] = w; w += mm; Xl[k] = w; w += mm; WE[k] = w; w += mm; WF[k] = w; w += mm; TA[k] = w; w += mm; TB[k] = w; w += mm;
+    }
+    double* U = w; w += m12;
+    double* T1 = w; w += m12;
+    double* WV[2] = {w, w + m1 * n1}; w += m1 * n1 + m2 * n2;
+    double* R1 = w;
+    VgGemmBatch g;
+    // 1. the four beta Gram matrices
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, c->beta, m2, 1, c->beta, 1, m2, Xa[0], (int)m1, (int)m1, (int)m1, (int)m2);    // beta beta^T
+    vg_gemm_add(&g, c->bl2, m2, 1, c->beta, 1, m2, Xl[0], (int)m1, (int)m1, (int)m1, (int)m2);     // (beta lam2) beta^T
+    vg_gemm_add(&g, c->beta, 1, m2, c->beta, m2, 1, Xa[1], (int)m2, (int)m2, (int)m2, (int)m1);    // beta^T beta
+    vg_gemm_add(&g, c->bl1, 1, m2, c->beta, m2, 1, Xl[1], (int)m2, (int)m2, (int)m2, (int)m1);     // (lam1 beta)^T beta
+    // ... and R1 = B1 Y^T (m1 x n2): the projection the step itself does not form
+    if (pts[1]) vg_gemm_add(&g, d1.BV, n1, 1, Y, 1, n1, R1, (int)n2, (int)m1, (int)n2, (int)n1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    // 2. weights
+    VG_HIP(vg_zw_launch(c->theta, 0, d1.lam0, d2.lam0, (int)m1, (int)m2, Xa[0], Xl[0], c->r1, c->r1l, WE[0], WF[0], st));
+    VG_HIP(vg_zw_launch(c->theta, 1, d2.lam0, d1.lam0, (int)m2, (int)m1, Xa[1], Xl[1], c->r2, c->r2l, WE[1], WF[1], st));
+    // 3. back to the original basis: W_M = Q W_E Q^T, W_H = Q (W_F + W_F^T) Q^T (Q = Qt^T), T1 = Q1 (beta / v^2) Q2^T
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, WE[k], d.m, 1, d.Qt, d.m, 1, TA[k], d.m, d.m, d.m, d.m);
+        vg_gemm_add(&g, WF[k], d.m, 1, d.Qt, d.m, 1, TB[k], d.m, d.m, d.m, d.m);
+    }
+    vg_gemm_add(&g, c->beta, m2, 1, d2.Qt, m2, 1, U, (int)m2, (int)m1, (int)m2, (int)m2, 1, 0, 1, 0, 1.0 / (v * v));
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, d.Qt, 1, d.m, TA[k], d.m, 1, WE[k], d.m, d.m, d.m, d.m);       // W_M -> WE
+        vg_gemm_add(&g, d.Qt, 1, d.m, TB[k], d.m, 1, WF[k], d.m, d.m, d.m, d.m);       // W_H -> WF
+    }
+    vg_gemm_add(&g, d1.Qt, 1, m1, U, m2, 1, T1, (int)m2, (int)m1, (int)m2, (int)m1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    // 4. W_V = s W_H B0 (+ the projection term in the next launch)
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        if (!pts[k]) continue;
+        vg_gemm_add(&g, WF[k], d.m, 1, d.BV, d.n, 1, WV[k], d.n, d.m, d.n, d.m, 1, 0, 1, 0, k ? s2 : s1);
+    }
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    const double rs = std::sqrt(s1 * s2);
+    if (pts[0]) {
+        const int ip = vg_gemm_add(&g, T1, m2, 1, c->St, n1, 1, WV[0], (int)n1, (int)m1, (int)n1, (int)m2, 1, 0, c->st_slabs, 2L * m2 * n1, rs, 1);
+        (void)ip;
+    }
+    if (pts[1]) {
+        vg_gemm_add(&g, T1, 1, m2, R1, n2, 1, WV[1], (int)n2, (int)m2, (int)n2, (int)m1, 1, 0, 1, 0, rs, 1);
+    }
+    VG_HIP(vg_gemm_launch(&g, st));
+    // 5. Abar = L0^-T W_V and Kbar = L0^-T W_M L0^-1 by substitution, in place (W_M sits in WE: first from the left, then -- on the
+    //    transposed view -- from the right).  Not through the explicit inverse: on RBF factors that costs digits (section 2 of
+    //    DESIGN.md), and here they are multiplied by 1 / (z_i - z_j).
+    for (int pass = 0; pass < 2; ++pass) {
+        VgTrsmSpec q[4];
+        int nq = 0;
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            if (!pts[k]) continue;
+            const bool dv = d.m <= VG_TRSM_BLK && d.Dinv0 && c->dinv_valid;
+            const double* dp = dv ? d.Dinv0 : d.Linv0;
+            const long blk = dv ? 256 : 16L * d.m + 16, dld = dv ? 16 : d.m;
+            if (pass == 0) {
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dp, blk, dld, WV[k], d.n, 1, d.n, d.m, 1};
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dp, blk, dld, WE[k], d.m, 1, d.m, d.m, 1};          // L^-T W_M
+            } else {
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dp, blk, dld, WE[k], 1, d.m, d.m, d.m, 1};          // (.) L^-1: L^-T on the transpose
+            }
+        }
+        if ((rc = trsm_batch(q, nq, st))) return rc;
+    }
+    // 6. contraction with d kappa / d z
+    if (pts[0]) VG_HIP(vg_zdot_launch(c->theta, 0, d1.grid, d1.x, (int)m1, n1, WV[0], d1.AD + m1 * n1, WE[0], d1.dK0, gz1, st));
+    if (pts[1]) VG_HIP(vg_zdot_launch(c->theta, 1, d2.grid, d2.x, (int)m2, n2, WV[1], d2.AD + m2 * n2, WE[1], d2.dK0, gz2, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}
+
 extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
     if (!c || !c->out) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host8, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost));

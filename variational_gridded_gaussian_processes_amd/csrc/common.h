@@ -255,6 +255,11 @@ struct VgMspace {
 };
 hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st);
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st);
+// inducing-point gradient (vggp_zgrad): weights of the gradient functional, and the row contraction with d kappa / d z
+hipError_t vg_zw_launch(const double* theta, int self, const double* lam_self, const double* lam_other, int m, int m_other,
+                        const double* X, const double* Xl, const double* r, const double* rl, double* WE, double* WFs, hipStream_t st);
+hipError_t vg_zdot_launch(const double* theta, int self, const double* z, const double* x, int m, long n, const double* Abar,
+                          const double* dA0, const double* Kbar, const double* dK0, double* out, hipStream_t st);
 
 // zero a handful of small device buffers with ONE kernel (used instead of hipMemsetAsync: memset nodes of a
 // captured graph were observed to replay with a wrong fill value after an unrelated hipMalloc on ROCm 7.2)

@@ -49,6 +49,8 @@ struct vggp_ctx {
     double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *ol = nullptr;
     double *out = nullptr, *theta = nullptr, *wq = nullptr;
     int st_split = 1, cc_split = 1;
+    int st_slabs = 1;                            // ... of S = [B2;V2] Y
+    bool dinv_valid = false;                     // Dinv0 holds the diagonal-block inverses of the current L0 (m <= 128 Cholesky path)
     int gh_slabs[2] = {1, 1}, cc_slabs = 1;      // split-K slab counts actually produced by the last partials launch
     long payload_len = 0;
     bool have_partials = false, have_step = false, have_masked = false;

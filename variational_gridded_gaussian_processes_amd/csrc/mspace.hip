@@ -316,3 +316,62 @@ hipError_t vg_clear_launch(const VgClearArgs* a, hipStream_t st) {
     hipLaunchKernelGGL(vg_clear_kernel, dim3(a->n), dim3(64), 0, st, *a);
     return hipGetLastError();
 }
+
+
+// ---- inducing-point gradient (vggp_zgrad, api.hip): the two element-wise stages ---------------------------------------------
+// Weights of the lengthscale-gradient formula seen as a linear functional of (Mk, V): dELBO = <W_E, Q^T Mk Q> + <W_F, Q^T (H + H^T) Q>
+// + <beta / v^2, P_d>  (oracle/kron.py z_grad).  One dimension per launch:
+//   W_E  = -X / (2 v^2) + diag(-r / 2 + m_o / 2 - So lam / (2 v)),   W_F = -Xl / (2 v^3) + diag(-rl / (2 v) + So / (2 v)),
+// lam = s_self lam0 (scaled eigenvalues), So = s_o sum(lam0_o); outputs W_E and W_F + W_F^T.
+__global__ __launch_bounds__(256) void vg_zw_kernel(const double* theta, int self, const double* lam_self, const double* lam_other,
+                                                   int m, int m_other, const double* X, const double* Xl, const double* r,
+                                                   const double* rl, double* WE, double* WFs) {
+    __shared__ double red[16];
+    const double s_self = theta[2 + self], s_o = theta[3 - self], v = theta[4];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < m_other; i += blockDim.x) t += lam_other[i];
+    t = vg_block_sum(t, red);
+    const double So = s_o * t;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)m * m; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / m), j = (int)(e - (long)i * m);
+        double we = -X[e] / (2.0 * v * v), wf = -(Xl[e] + Xl[(long)j * m + i]) / (2.0 * v * v * v);
+        if (i == j) {
+            we += -0.5 * r[i] + 0.5 * (double)m_other - So * s_self * lam_self[i] / (2.0 * v);
+            wf += 2.0 * (-0.5 * rl[i] / v + So / (2.0 * v));
+        }
+        WE[e] = we;
+        WFs[e] = wf;
+    }
+}
+hipError_t vg_zw_launch(const double* theta, int self, const double* lam_self, const double* lam_other, int m, int m_other,
+                        const double* X, const double* Xl, const double* r, const double* rl, double* WE, double* WFs, hipStream_t st) {
+    hipLaunchKernelGGL(vg_zw_kernel, dim3((unsigned)((m * m + 255) / 256)), dim3(256), 0, st, theta, self, lam_self, lam_other, m, m_other,
+                       X, Xl, r, rl, WE, WFs);
+    return hipGetLastError();
+}
+
+// g_i = -ell [ sum_k Abar_ik dA0_ik / (z_i - x_k) + sum_{j != i} (Kbar_ij + Kbar_ji) dK0_ij / (z_i - z_j) ]: for a stationary kernel
+// d kappa(z_i, x) / d z_i = -(d kappa / d ell) ell / (z_i - x) (0 where z_i = x).  One workgroup per inducing point.
+__global__ __launch_bounds__(256) void vg_zdot_kernel(const double* theta, int self, const double* z, const double* x, int m, long n,
+                                                     const double* Abar, const double* dA0, const double* Kbar, const double* dK0,
+                                                     double* out) {
+    __shared__ double red[16];
+    const int i = blockIdx.x;
+    const double zi = z[i];
+    double acc = 0.0;
+    for (long k = threadIdx.x; k < n; k += blockDim.x) {
+        const double d = zi - x[k];
+        if (d != 0.0) acc += Abar[(long)i * n + k] * dA0[(long)i * n + k] / d;
+    }
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        const double d = zi - z[j];
+        if (j != i && d != 0.0) acc += (Kbar[(long)i * m + j] + Kbar[(long)j * m + i]) * dK0[(long)i * m + j] / d;
+    }
+    acc = vg_block_sum(acc, red);
+    if (threadIdx.x == 0) out[i] = -theta[self] * acc;
+}
+hipError_t vg_zdot_launch(const double* theta, int self, const double* z, const double* x, int m, long n, const double* Abar,
+                          const double* dA0, const double* Kbar, const double* dK0, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(vg_zdot_kernel, dim3(m), dim3(256), 0, st, theta, self, z, x, m, n, Abar, dA0, Kbar, dK0, out);
+    return hipGetLastError();
+}

@@ -232,6 +232,14 @@ class Engine:
         check(fn(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(cov), _stream(self.device)))
         return cov
 
+    def zgrad(self, Y: torch.Tensor):
+        """d ELBO / d z of the last elbo_step(Y, ...) for the inducing coordinates of both dimensions ("points" bases; zeros
+        otherwise) -> (g1 [m1], g2 [m2]) device tensors."""
+        g1 = torch.empty(self.m1, dtype=torch.float64, device=self.device)
+        g2 = torch.empty(self.m2, dtype=torch.float64, device=self.device)
+        check(self.lib.vggp_zgrad(self._h, _ptr(Y), _ptr(g1), _ptr(g2), _stream(self.device)))
+        return g1, g2
+
     def qv_cov_masked(self) -> torch.Tensor:
         M = self.m1 * self.m2
         cov = torch.empty(M, M, dtype=torch.float64, device=self.device)

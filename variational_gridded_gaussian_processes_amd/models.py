@@ -131,7 +131,7 @@ class _ElboFunction(torch.autograd.Function):
     """value + analytic gradient from one vggp_elbo_step; backward only scales the cached gradient."""
 
     @staticmethod
-    def forward(ctx, theta: torch.Tensor, model: "KroneckerStructure"):
+    def forward(ctx, theta: torch.Tensor, model: "KroneckerStructure", Z: Optional[torch.Tensor] = None):
         try:
             elbo, grad, info = model._engine_step([float(t) for t in theta.detach().cpu()])
         except VggpError as e:
@@ -139,13 +139,20 @@ class _ElboFunction(torch.autograd.Function):
                 raise torch.linalg.LinAlgError(str(e)) from e
             raise
         model.last_info = info
-        ctx.save_for_backward(torch.as_tensor(grad, dtype=theta.dtype, device=theta.device))
+        gz = None
+        if Z is not None and Z.requires_grad:
+            # trainable inducing points (the reference registers Z as a Parameter, kronecker_structure.py:303-304, and autograd
+            # reaches it through kernel(Z)): analytic gradient from the engine's resident state (vggp_zgrad)
+            g1, g2 = model._engine.zgrad(model._Y)
+            cols = [g1] if Z.shape[1] == 1 else [g1, g2]
+            gz = torch.stack(cols, dim=1).to(dtype=Z.dtype, device=Z.device)
+        ctx.save_for_backward(torch.as_tensor(grad, dtype=theta.dtype, device=theta.device), gz)
         return torch.as_tensor(elbo, dtype=theta.dtype, device=theta.device)
 
     @staticmethod
     def backward(ctx, grad_out):
-        (g,) = ctx.saved_tensors
-        return grad_out * g, None
+        g, gz = ctx.saved_tensors
+        return grad_out * g, None, (grad_out * gz if gz is not None else None)
 
 
 def _detect_grid(X: torch.Tensor):
@@ -557,11 +564,16 @@ class Matern12B1SplineASVGP(KroneckerStructure):
 class Matern12SVGP(KroneckerStructure):
     """kronecker_structure.py:287-338: Z (m, 2) holds the per-dimension inducing coordinates; the inducing set
     is cartesian_prod(Z[:,0], Z[:,1]) (:336), so Kuu = kron(K1(Z[:,0]), K2(Z[:,1])) (:318-321).
-    Z is kept as a buffer-like Parameter with requires_grad=False (its gradient is a 'next' item)."""
+    Z is a trainable Parameter as in the reference (:303-304): `_elbo()` carries its analytic gradient (vggp_zgrad) unless
+    `train_z=False`.  A step with moved inducing points re-plans the engine (new factors, cold eigensolver start).  On a masked
+    grid (X a subset of a cartesian grid) Z stays fixed: the masked step has no Z-gradient yet."""
 
-    def __init__(self, X, y, Z: torch.Tensor, **kw):
+    def __init__(self, X, y, Z: torch.Tensor, train_z: bool = True, **kw):
         super().__init__(X, y, **kw)
-        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=False)
+        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=bool(train_z) and not self._masked)
+
+    def _elbo(self) -> torch.Tensor:
+        return _ElboFunction.apply(self._theta(), self, self.Z)
 
     def _basis(self):
         Z = self.Z.detach().cpu().numpy()
@@ -693,10 +705,13 @@ class univariate:
     class Matern12SVGP(_SparseGP1D):
         """univariate_structure.py:273-332."""
 
-        def __init__(self, X, y, Z, **kw):
+        def __init__(self, X, y, Z, train_z: bool = True, **kw):
             super().__init__(X, y, **kw)
             self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).reshape(-1, 1).clone(),
-                                        requires_grad=False)
+                                        requires_grad=bool(train_z))
+
+        def _elbo(self):
+            return _ElboFunction.apply(self._theta(), self, self.Z)
 
         def _basis(self):
             return "points", self.Z.detach().cpu().numpy().reshape(-1).copy()
