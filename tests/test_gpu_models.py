@@ -419,3 +419,23 @@ def test_svgp_trainable_inducing_points_vs_dense_autograd(engine, cls, kind):
     fixed = getattr(M, cls)(torch.tensor(X), torch.tensor(y), Z, engine=engine, train_z=False).to(torch.float64)
     fixed._elbo().backward()
     assert fixed.Z.grad is None
+
+
+def test_univariate_svgp_trainable_inducing_points(engine):
+    """1-D twin (univariate_structure.py:273-332, Z a trainable Parameter): Z.grad against autograd through the dense 1-D
+    restatement."""
+    from variational_gridded_gaussian_processes_amd.models import univariate
+    rng = np.random.default_rng(2)
+    n, m = 60, 9
+    x = np.linspace(0, 1, n)
+    y = np.sin(7 * x) + 0.1 * rng.standard_normal(n)
+    z = np.sort(rng.uniform(0.05, 0.95, m))
+    model = univariate.Matern32SVGP(torch.tensor(x), torch.tensor(y), torch.tensor(z), engine=engine).to(torch.float64)
+    dm = D.Dense1D(x, y, "points", "matern32", torch.tensor(z))
+    dm.grid.requires_grad_(True)
+    e = model._elbo()
+    e.backward()
+    ed = dm._elbo()
+    ed.backward()
+    assert abs(e.item() - ed.item()) <= 1e-6 * abs(ed.item())
+    assert rel(model.Z.grad.numpy().reshape(-1), dm.grid.grad.numpy()) < 1e-5
