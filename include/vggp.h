@@ -198,6 +198,11 @@ int vggp_qv_cov(vggp_ctx* ctx, double* cov, void* stream);
  * Single-rank contexts only (VGGP_ESTATE otherwise). */
 int vggp_zgrad(vggp_ctx* ctx, const double* Y, double* gz1, double* gz2, void* stream);
 
+/* New inducing coordinates z[0..m) (host array) for dimension dim (0 or 1) of a planned context whose basis there is
+ * VGGP_BASIS_POINTS, without re-planning: arena, captured graphs and the eigensolver's warm start are kept.  What an optimiser
+ * that trains Z (kronecker_structure.py:303-304 registers it as a Parameter) calls between steps.  Read-outs need a new step. */
+int vggp_set_inducing(vggp_ctx* ctx, int dim, const double* z, int64_t m);
+
 /* Point-wise posterior at ns scattered test points (xs1[p], xs2[p]) (DEVICE inputs):
  * mean[ns], var[ns] (DEVICE).  Replaces KroneckerStructure.posterior mean and the
  * diagonal of its covariance (kronecker_structure.py:199-230). */

@@ -343,6 +343,24 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     return VGGP_OK;
 }
 
+// New coordinates for the inducing points of a "points" basis WITHOUT re-planning: the device array is overwritten in place, so
+// the arena, the captured graphs (they hold the pointer, not the values) and the warm start all stay -- a small move of Z changes
+// the Gram matrices as little as a small move of the lengthscale does, and the subspace start checks itself (VG_ESUBMISS).  This
+// is what an optimiser that trains Z (kronecker_structure.py:303-304) calls between steps.
+extern "C" int vggp_set_inducing(vggp_ctx* c, int dim, const double* z, int64_t m) {
+    if (!c || !c->planned) { vg_set_error("vggp_set_inducing: context not planned"); return VGGP_ESTATE; }
+    VG_REQUIRE(dim == 0 || dim == 1, "vggp_set_inducing: dim must be 0 or 1");
+    VgDim& d = c->d[dim];
+    VG_REQUIRE(d.basis == VGGP_BASIS_POINTS, "vggp_set_inducing: dimension %d does not use the points basis", dim + 1);
+    VG_REQUIRE(z && m == d.m, "vggp_set_inducing: expected %d coordinates, got %lld", d.m, (long long)m);
+    for (int64_t i = 0; i < m; ++i) VG_REQUIRE(std::isfinite(z[i]), "vggp_set_inducing: z[%lld] is not finite", (long long)i);
+    VG_ENTER_DEVICE(c->device);
+    VG_HIP(hipStreamSynchronize(c->own_stream));              // no step of this context is reading the old coordinates
+    VG_HIP(hipMemcpy(d.grid, z, sizeof(double) * m, hipMemcpyHostToDevice));
+    c->have_step = false; c->have_partials = false; c->have_masked = false; c->acc_valid = false;      // read-outs need a new step
+    return VGGP_OK;
+}
+
 extern "C" int64_t vggp_payload_len(const vggp_ctx* c) { return (c && c->planned) ? c->payload_len : 0; }
 extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t)c->arena_used : 0; }
 

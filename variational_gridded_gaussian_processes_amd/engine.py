@@ -232,6 +232,12 @@ class Engine:
         check(fn(self._h, _ptr(xs1), _ptr(xs2), ns, _ptr(cov), _stream(self.device)))
         return cov
 
+    def set_inducing(self, dim: int, z) -> None:
+        """Move the inducing points of a 'points' basis (dimension 0 or 1) without re-planning: graphs and warm start stay."""
+        zz = _dvec(z)
+        with torch.cuda.device(self.device):
+            check(self.lib.vggp_set_inducing(self._h, int(dim), zz.ctypes.data, len(zz)))
+
     def zgrad(self, Y: torch.Tensor):
         """d ELBO / d z of the last elbo_step(Y, ...) for the inducing coordinates of both dimensions ("points" bases; zeros
         otherwise) -> (g1 [m1], g2 [m2]) device tensors."""

@@ -230,7 +230,15 @@ class KroneckerStructure(torch.nn.Module):
         factors, basis, meshes -- lives in the engine) or when its inducing description changed since the last plan."""
         basis, g1, g2 = self._basis()
         key = (basis, np.asarray(g1).tobytes(), np.asarray(g2).tobytes())
-        if not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
+        if self._planned and self._plan_token == self._engine.plan_token and key != self._plan_key and basis == "points" \
+                and self._plan_key is not None and len(self._plan_key[1]) == len(key[1]) and len(self._plan_key[2]) == len(key[2]):
+            # only the inducing points moved (an optimiser training Z): new coordinates in place, plan / graphs / warm start stay
+            if key[1] != self._plan_key[1]:
+                self._engine.set_inducing(0, g1)
+            if key[2] != self._plan_key[2]:
+                self._engine.set_inducing(1, g2)
+            self._plan_key = key
+        elif not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
             self._engine.plan(self.kind, basis, g1, self._x1, self.kind, basis, g2, self._x2, warm_start=self._warm,
                               b0_f32_kdelta=self._f32_mesh())
             self._planned = True
@@ -565,7 +573,7 @@ class Matern12SVGP(KroneckerStructure):
     """kronecker_structure.py:287-338: Z (m, 2) holds the per-dimension inducing coordinates; the inducing set
     is cartesian_prod(Z[:,0], Z[:,1]) (:336), so Kuu = kron(K1(Z[:,0]), K2(Z[:,1])) (:318-321).
     Z is a trainable Parameter as in the reference (:303-304): `_elbo()` carries its analytic gradient (vggp_zgrad) unless
-    `train_z=False`.  A step with moved inducing points re-plans the engine (new factors, cold eigensolver start).  On a masked
+    `train_z=False`.  Moved inducing points reach the engine through vggp_set_inducing (no re-plan: graphs and warm start stay).  On a masked
     grid (X a subset of a cartesian grid) Z stays fixed: the masked step has no Z-gradient yet."""
 
     def __init__(self, X, y, Z: torch.Tensor, train_z: bool = True, **kw):
@@ -622,7 +630,11 @@ class _SparseGP1D(torch.nn.Module):
     def _plan(self):
         basis, g = self._basis()
         key = (basis, np.asarray(g).tobytes())
-        if not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
+        if self._planned and self._plan_token == self._engine.plan_token and key != self._plan_key and basis == "points" \
+                and self._plan_key is not None and len(self._plan_key[1]) == len(key[1]):
+            self._engine.set_inducing(0, g)          # only Z moved
+            self._plan_key = key
+        elif not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
             mesh = getattr(self, "mesh", None)
             self._engine.plan(self.kind, basis, g, self._x, "matern12", "one", None, np.zeros(1), warm_start=self._warm,
                               b0_f32_kdelta=mesh is not None and mesh.dtype == torch.float32)
