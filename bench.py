@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   stages_us         per-launch-group breakdown of one step (HIP events on the launch stream, plain launches)
   cold_ms_per_step  the same loop with the eigensolver's warm start off
   m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
+  svgp_train_z      ms per optimiser iteration of an SVGP whose inducing points are trained (step + Z-gradient + in-place move)
   slab_1024x4096    the per-rank shape of BASELINE configs[3]: ms per step, and the projection kernel's MFMA fraction at that size
   kron_solve        BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
   factor_build      HBM-write rate of the factor kernel at m = n = 8192
@@ -355,6 +356,7 @@ def main():
             out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=40 if md < 256 else 12,
                                                     warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
             out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
+            out["svgp_train_z"] = trainz_bench(eng, Y, yy, x1, x2, m)
             out["kron_solve"] = kron_solve_bench(eng, 1024)
             out["factor_build"] = factor_build_bench(eng)
         if not args.no_cpu and world == 1 and not args.masked:
@@ -414,6 +416,36 @@ def slab_bench(eng, D, kind, m, n1=4096, n2=1024):
     return {"ms_per_step": ms, "grid_points_per_s": n1 * n2 / (ms * 1e-3), "project_kernel": eng.project_kernel_name(),
             "project_us": us, "project_flops": fl, "project_TFLOP/s": fl / (us * 1e-6) / 1e12,
             "project_frac_of_fp64_peak": fl / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS}
+
+
+def trainz_bench(eng, Y, yy, x1, x2, m, kind="matern32", steps=60, warmup=15):
+    """SVGP with trainable inducing points (kronecker_structure.py:303-304): ms per optimiser iteration = vggp_elbo_step +
+    vggp_zgrad + vggp_set_inducing (Adam on the 5 hyper-parameters and on both coordinate vectors), same 1024 x 1024 grid."""
+    import torch
+    z = [np.linspace(0, 1, m), np.linspace(0, 1, m)]
+    eng.plan(kind, "points", z[0], x1, kind, "points", z[1], x2, warm_start=True)
+    opt = Adam(raw_start(), lr=0.01)
+    oz = [Adam(z[0].copy(), lr=1e-4), Adam(z[1].copy(), lr=1e-4)]
+
+    def one():
+        raw = opt.x
+        e, gr, info = eng.elbo_step(Y, yy, theta_from_raw(raw.copy()))
+        g1, g2 = eng.zgrad(Y)
+        opt.step(-(gr / (1.0 + np.exp(-raw))))
+        for d, g in enumerate((g1, g2)):
+            oz[d].step(-g.cpu().numpy())
+            eng.set_inducing(d, oz[d].x)
+        return e
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e = one()
+    torch.cuda.synchronize()
+    return {"kind": kind, "ms_per_iteration": (time.perf_counter() - t0) / steps * 1e3, "elbo_last": e,
+            "what": "elbo_step + zgrad + set_inducing x2, inducing points and hyper-parameters trained together"}
 
 
 def factor_build_bench(eng, n=8192, reps=5):
