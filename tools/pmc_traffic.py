@@ -24,7 +24,7 @@ write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 calib, _ = per_kernel(sys.argv[3], "FETCH_SIZE")
 n1, n2, m = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
 cal_bytes = float(os.environ.get("CALIB_BYTES", 0))
-k = "vg_gemm_gram_project_wide_kernel" if "vg_gemm_gram_project_wide_kernel" in fetch else "vg_gemm_gram_project_kernel"
+k = next(n for n in ("vg_gemm_project_deep_kernel", "vg_gemm_gram_project_wide_kernel", "vg_gemm_gram_project_kernel") if n in fetch)
 ck = "vg_sumsq_kernel"
 factor = cal_bytes / (calib[ck] * 1024.0)
 alg = 8 * (n1 * n2 + 2 * m * n2 + 2 * m * n1)

@@ -18,6 +18,7 @@
 //                           two k rows of a 32-lane LDS group use disjoint bank halves)
 #include "gemm_body.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
@@ -35,6 +36,91 @@ __global__ __launch_bounds__(256) void vg_gemm_gram_project_kernel(const VgGemmB
 __global__ __launch_bounds__(512) void vg_gemm_gram_project_wide_kernel(const VgGemmBatch b) {
     __shared__ double lds[2 * VgTile<64, 16>::TILE];
     vg_gemm_body<64, 16, 512>(b, lds, blockIdx.x);
+}
+// Deep-stage variant for the one launch whose shape is known in advance -- S = [B2;V2] Y: A K-contiguous, B N-contiguous, whole
+// 64 x 64 tiles, k-chunks that are multiples of 32, XCD-grouped block order -- 64 x 64 x 32 stages: every thread moves one 16-byte
+// load per operand and stage (all of a stage's loads in flight together, the next stage prefetched into registers) and the
+// workgroup meets at 2 barriers per 32 k instead of per 16.  tools/ubench/project.hip: 14.2 vs 15.8 us per launch back to back,
+// bit-identical slabs (same k order).
+typedef double vg_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void vg_gemm_project_deep_kernel(const VgGemmBatch b) {
+    constexpr int T = 64, NT = 512, BK = 32;
+    constexpr int RS = BK + 2;                    // A tile in LDS [row][BK + 2]: fragment lanes (i, fk) -> 2 i + fk: distinct banks
+    constexpr int KS = T + 16;                    // B tile in LDS [k][80]
+    constexpr int NA = T * BK / (2 * NT);         // double2 loads per thread, operand and stage
+    __shared__ __attribute__((aligned(16))) double lds[T * RS + BK * KS];
+    double* As = lds;
+    double* Bs = lds + T * RS;
+    const VgGemmP& p = b.p[0];
+    const int t = blockIdx.x;
+    const int nx = 8 / p.ksplit;
+    const int xcd = t & 7, j = t >> 3;
+    const int ks = xcd / nx;
+    const int gi = j / p.tiles_m;
+    const int tm = j - gi * p.tiles_m;
+    const int tn = gi * nx + (xcd - ks * nx);
+    const int row0 = tm * T, col0 = tn * T, k_begin = ks * p.kchunk;
+    const int kend = min(p.K, k_begin + p.kchunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;      // 2 x 4 waves, each 32 rows x 16 columns
+    const int fi = lane & 15, fk = lane >> 4;
+    const long lda = p.sa_m, ldb = p.sb_k;
+    const double* pa[NA];
+    const double* pb[NA];
+    int la[NA], lb[NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+        const int idx = tid + r * NT;
+        const int arow = idx / (BK / 2), akp = idx % (BK / 2);
+        pa[r] = p.A + (long)(row0 + arow) * lda + k_begin + 2 * akp;
+        la[r] = arow * RS + 2 * akp;
+        const int bk = idx / 32, bcp = idx % 32;
+        pb[r] = p.B + (long)(k_begin + bk) * ldb + col0 + 2 * bcp;
+        lb[r] = bk * KS + 2 * bcp;
+    }
+    vg_d2 ra[NA], rb[NA];
+    auto ld = [&]() {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) { ra[r] = *reinterpret_cast<const vg_d2*>(pa[r]); rb[r] = *reinterpret_cast<const vg_d2*>(pb[r]); }
+#pragma unroll
+        for (int r = 0; r < NA; ++r) { pa[r] += BK; pb[r] += (long)BK * ldb; }
+    };
+    vg_d4 acc[2] = {(vg_d4){0.0, 0.0, 0.0, 0.0}, (vg_d4){0.0, 0.0, 0.0, 0.0}};
+    const int nst = (kend - k_begin) / BK;
+    if (nst > 0) ld();
+    for (int s = 0; s < nst; ++s) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            *reinterpret_cast<vg_d2*>(As + la[r]) = ra[r];
+            *reinterpret_cast<vg_d2*>(Bs + lb[r]) = rb[r];
+        }
+        __syncthreads();
+        if (s + 1 < nst) ld();
+        const double* ap0 = As + (wr * 32 + fi) * RS + fk;
+        const double* ap1 = ap0 + 16 * RS;
+        const double* bp = Bs + fk * KS + wc * 16 + fi;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            const double a0 = ap0[kk], a1 = ap1[kk], b0 = bp[kk * KS];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double* Cs = p.C + (long)ks * p.c_slab;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Cs[(long)(row0 + wr * 32 + mb * 16 + fk + 4 * r) * p.ldc + col0 + wc * 16 + fi] = p.alpha * acc[mb][r];
+}
+static bool vg_project_deep_ok(const VgGemmBatch* b) {
+    static const bool off = getenv("VGGP_NO_DEEP_PROJECT") != nullptr;
+    if (off || b->nprob != 1) return false;
+    const VgGemmP& p = b->p[0];
+    return p.xcd_group && p.sa_k == 1 && p.sb_n == 1 && (p.sa_m % 2) == 0 && (p.sb_k % 2) == 0 && (p.M % 64) == 0 && (p.N % 64) == 0 &&
+           (p.kchunk % 32) == 0 && (p.K % 32) == 0 && p.b_nslab == 1 && p.a_nslab == 1 && p.tri == VG_TRI_NONE && !p.accum &&
+           !p.dotw && !p.dot_out && p.C && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0;
 }
 __global__ __launch_bounds__(512) void vg_gemm_wide_kernel(const VgGemmBatch b) {      // the same 8-wave tile for other launches
     __shared__ double lds[2 * VgTile<64, 16>::TILE];
@@ -117,7 +203,10 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
     }
     static const bool wide = getenv("VGGP_GEMM_NARROW") == nullptr;
     // (a 64 x 64 x 32 k-tile variant of the wide kernel -- half the barriers per MFMA -- was measured SLOWER: 28.6 vs 23.5 us)
-    if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && b->total_tiles <= 320) {
+    if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && vg_project_deep_ok(b)) {
+        g_last_project_kernel = "vg_gemm_project_deep_kernel";
+        hipLaunchKernelGGL(vg_gemm_project_deep_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
+    } else if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && b->total_tiles <= 320) {
         g_last_project_kernel = "vg_gemm_gram_project_wide_kernel";
         hipLaunchKernelGGL(vg_gemm_gram_project_wide_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
     } else if (tag == VG_GEMM_TAG_GRAM_PROJECT) {
