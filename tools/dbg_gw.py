@@ -1,6 +1,7 @@
-"""Structure of the matrices the two eigensolver launches of a warm RBF step start from (Gw = E G E^T and the Ritz matrix
-H = V1 G V1^T): how many off-diagonal elements exceed the solver's threshold, and where (range x range, range x null,
-null x null)."""
+"""Structure of the matrix the main eigensolver launch of a warm RBF step starts from (Gw = E G E^T): how many off-diagonal
+elements exceed the solver's threshold, and where (range x range, range x null, null x null).  (The Ritz-matrix part reads the
+buffer Hs, which the step no longer fills since the Ritz launch forms H = T V1^T itself: run it on a commit before that change,
+or ignore those lines.)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
