@@ -71,6 +71,7 @@ struct VgGemmP {
     const double* dotw;
     double* dot_out;
     int dotw_ld;
+    int deep;          // set by vg_gemm_launch: this problem runs on the deep-stage tile (gemm.hip vg_gemm_deep_body)
 };
 #define VG_TRI_NONE 0
 #define VG_TRI_A_LOWER 1   // op(A)[i][k] = 0 for k > i:  k < roundup128(row0 + T)

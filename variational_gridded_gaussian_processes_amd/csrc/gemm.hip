@@ -122,6 +122,120 @@ static bool vg_project_deep_ok(const VgGemmBatch* b) {
            (p.kchunk % 32) == 0 && (p.K % 32) == 0 && p.b_nslab == 1 && p.a_nslab == 1 && p.tri == VG_TRI_NONE && !p.accum &&
            !p.dotw && !p.dot_out && p.C && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0;
 }
+// The deep-stage tile for ANY qualifying problem of a batch (whole 64 x 64 tiles, k-chunks that are multiples of 32, each operand
+// contiguous along one of its two axes with 16-byte aligned rows, plain operands): the four orientation combinations differ only in
+// how a stage is laid out in LDS -- K-contiguous [row][34], M/N-contiguous [k][80] -- exactly as in the generic body.  Written for
+// the masked assembly (config 5: two 8.6 GFLOP and three 4.3 GFLOP products per step, which the 64 x 64 x 16 body runs at 24 TF/s).
+__device__ __forceinline__ void vg_gemm_deep_body(const VgGemmP& p, double* lds, int t) {
+    constexpr int T = 64, NT = 512, BK = 32, RS = BK + 2, KS = T + 16, NA = T * BK / (2 * NT);
+    constexpr int TILE = BK * KS > T * RS ? BK * KS : T * RS;
+    double* As = lds;
+    double* Bs = lds + TILE;
+    const int tiles = p.tiles_m * p.tiles_n;
+    int ks, tm, tn;
+    if (p.xcd_group) {
+        const int nx = 8 / p.ksplit;
+        const int xcd = t & 7, j = t >> 3;
+        ks = xcd / nx;
+        const int gi = j / p.tiles_m;
+        tm = j - gi * p.tiles_m;
+        tn = gi * nx + (xcd - ks * nx);
+    } else {
+        ks = t / tiles;
+        t -= ks * tiles;
+        tm = t / p.tiles_n;
+        tn = t - tm * p.tiles_n;
+    }
+    const int row0 = tm * T, col0 = tn * T, k_begin = ks * p.kchunk, k_end = min(p.K, k_begin + p.kchunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;      // 2 x 4 waves, each 32 rows x 16 columns
+    const int fi = lane & 15, fk = lane >> 4;
+    const bool a_kc = p.sa_k == 1, b_nc = p.sb_n == 1;
+    const double* pa[NA];
+    const double* pb[NA];
+    int la[NA], lb[NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+        const int idx = tid + r * NT;
+        if (a_kc) { const int row = idx / (BK / 2), kp = idx % (BK / 2); pa[r] = p.A + (long)(row0 + row) * p.sa_m + k_begin + 2 * kp; la[r] = row * RS + 2 * kp; }
+        else      { const int k = idx / (T / 2), rp = idx % (T / 2);    pa[r] = p.A + (long)(k_begin + k) * p.sa_k + row0 + 2 * rp;  la[r] = k * KS + 2 * rp; }
+        if (b_nc) { const int k = idx / (T / 2), cp = idx % (T / 2);    pb[r] = p.B + (long)(k_begin + k) * p.sb_k + col0 + 2 * cp;  lb[r] = k * KS + 2 * cp; }
+        else      { const int col = idx / (BK / 2), kp = idx % (BK / 2); pb[r] = p.B + (long)(col0 + col) * p.sb_n + k_begin + 2 * kp; lb[r] = col * RS + 2 * kp; }
+    }
+    const long da = a_kc ? BK : (long)BK * p.sa_k, db = b_nc ? (long)BK * p.sb_k : BK;
+    vg_d2 ra[NA], rb[NA];
+    auto ld = [&]() {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) { ra[r] = *reinterpret_cast<const vg_d2*>(pa[r]); rb[r] = *reinterpret_cast<const vg_d2*>(pb[r]); }
+#pragma unroll
+        for (int r = 0; r < NA; ++r) { pa[r] += da; pb[r] += db; }
+    };
+    const int a_si = a_kc ? RS : 1, a_sk = a_kc ? 1 : KS, b_sj = b_nc ? 1 : RS, b_sk = b_nc ? KS : 1;
+    vg_d4 acc[2] = {(vg_d4){0.0, 0.0, 0.0, 0.0}, (vg_d4){0.0, 0.0, 0.0, 0.0}};
+    const int nst = (k_end - k_begin) / BK;
+    if (nst > 0) ld();
+    for (int s = 0; s < nst; ++s) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            *reinterpret_cast<vg_d2*>(As + la[r]) = ra[r];
+            *reinterpret_cast<vg_d2*>(Bs + lb[r]) = rb[r];
+        }
+        __syncthreads();
+        if (s + 1 < nst) ld();
+        const double* ap0 = As + (wr * 32 + fi) * a_si + fk * a_sk;
+        const double* ap1 = ap0 + 16 * a_si;
+        const double* bp = Bs + fk * b_sk + (wc * 16 + fi) * b_sj;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            const double a0 = ap0[kk * a_sk], a1 = ap1[kk * a_sk], b0 = bp[kk * b_sk];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double* Cs = p.C + (long)ks * p.c_slab;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* cp = Cs + (long)(row0 + wr * 32 + mb * 16 + fk + 4 * r) * p.ldc + col0 + wc * 16 + fi;
+            const double v = p.alpha * acc[mb][r];
+            *cp = p.accum ? *cp + v : v;
+        }
+}
+static bool vg_deep_ok(const VgGemmP& p) {
+    const bool a_kc = p.sa_k == 1, a_mc = p.sa_m == 1, b_nc = p.sb_n == 1, b_kc = p.sb_k == 1;
+    if (!(a_kc || a_mc) || !(b_nc || b_kc)) return false;
+    const long lda = a_kc ? p.sa_m : p.sa_k, ldb = b_nc ? p.sb_k : p.sb_n;
+    return (p.M % 64) == 0 && (p.N % 64) == 0 && (p.K % 32) == 0 && (p.kchunk % 32) == 0 && p.a_nslab == 1 && p.b_nslab == 1 &&
+           p.tri == VG_TRI_NONE && !p.dotw && !p.dot_out && p.C && (lda % 2) == 0 && (ldb % 2) == 0 &&
+           ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0;
+}
+static bool vg_deep_batch(const VgGemmBatch* b, VgGemmBatch* out) {
+    static const bool off = getenv("VGGP_NO_DEEP_GEMM") != nullptr;
+    static const char* mt = getenv("VGGP_DEEP_MIN_TILES");
+    const int min_tiles = mt ? atoi(mt) : 128;
+    if (off || b->total_tiles < min_tiles) return false;
+    *out = *b;
+    long deep_tiles = 0;
+    for (int i = 0; i < out->nprob; ++i) {
+        VgGemmP& p = out->p[i];
+        p.deep = vg_deep_ok(p) ? 1 : 0;
+        if (p.deep) deep_tiles += (long)p.tiles_m * p.tiles_n * p.ksplit;
+    }
+    return 4 * deep_tiles >= 3L * out->total_tiles;
+}
+// mixed batches: deep body for the problems flagged by the host (VgGemmP::deep), the generic 8-wave tile for the others
+__global__ __launch_bounds__(512) void vg_gemm_deep_kernel(const VgGemmBatch b) {
+    constexpr int DT = 32 * 80 > 64 * 34 ? 32 * 80 : 64 * 34;
+    __shared__ __attribute__((aligned(16))) double lds[2 * DT];
+    const int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < b.nprob; ++i)
+        if (bid >= b.p[i].tile_start) pi = i;
+    if (b.p[pi].deep) vg_gemm_deep_body(b.p[pi], lds, bid - b.p[pi].tile_start);
+    else vg_gemm_body<64, 16, 512>(b, lds, bid);
+}
 __global__ __launch_bounds__(512) void vg_gemm_wide_kernel(const VgGemmBatch b) {      // the same 8-wave tile for other launches
     __shared__ double lds[2 * VgTile<64, 16>::TILE];
     vg_gemm_body<64, 16, 512>(b, lds, blockIdx.x);
@@ -160,7 +274,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     p.a_slab = 0;
     p.tri = VG_TRI_NONE;
     p.xcd_group = 0;
-    p.dotw = nullptr; p.dot_out = nullptr; p.dotw_ld = 0;
+    p.dotw = nullptr; p.dot_out = nullptr; p.dotw_ld = 0; p.deep = 0;
     p.tiles_m = (M + VG_BM - 1) / VG_BM;
     p.tiles_n = (N + VG_BN - 1) / VG_BN;
     p.tile_start = b->total_tiles;
@@ -176,6 +290,11 @@ void vg_gemm_xcd_group(VgGemmBatch* b, int prob) {
                     (p.tiles_n % (8 / p.ksplit)) == 0;
     p.xcd_group = ok ? 1 : 0;
 }
+
+// The deep-stage kernel takes a launch of at least 128 tiles of which at least three quarters qualify (same-box sweep of
+// VGGP_DEEP_MIN_TILES, tools/ab_masked.sh: masked 2048^2 step 2.18 -> 2.02 ms, 1024^2 step 275.8 -> 271.6 us -- its Gram launch --
+// nothing more below 128).  VGGP_NO_DEEP_GEMM=1: off.
+static bool vg_deep_batch(const VgGemmBatch* b, VgGemmBatch* out);
 
 static const char* g_last_project_kernel = "";
 const char* vg_last_project_kernel() { return g_last_project_kernel; }
@@ -202,6 +321,7 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
         return hipGetLastError();
     }
     static const bool wide = getenv("VGGP_GEMM_NARROW") == nullptr;
+    VgGemmBatch deepb;
     // (a 64 x 64 x 32 k-tile variant of the wide kernel -- half the barriers per MFMA -- was measured SLOWER: 28.6 vs 23.5 us)
     if (tag == VG_GEMM_TAG_GRAM_PROJECT && wide && vg_project_deep_ok(b)) {
         g_last_project_kernel = "vg_gemm_project_deep_kernel";
@@ -212,6 +332,9 @@ hipError_t vg_gemm_launch(const VgGemmBatch* b, hipStream_t st, int tag) {
     } else if (tag == VG_GEMM_TAG_GRAM_PROJECT) {
         g_last_project_kernel = "vg_gemm_gram_project_kernel";
         hipLaunchKernelGGL(vg_gemm_gram_project_kernel, dim3(b->total_tiles), dim3(256), 0, st, *b);
+    }
+    else if (vg_deep_batch(b, &deepb)) {
+        hipLaunchKernelGGL(vg_gemm_deep_kernel, dim3(deepb.total_tiles), dim3(512), 0, st, deepb);
     }
     else if (tag == VG_GEMM_TAG_WIDE && wide && b->total_tiles <= 320)
         hipLaunchKernelGGL(vg_gemm_wide_kernel, dim3(b->total_tiles), dim3(512), 0, st, *b);
