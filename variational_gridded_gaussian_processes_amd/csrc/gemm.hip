@@ -146,7 +146,14 @@ __device__ __forceinline__ void vg_gemm_deep_body(const VgGemmP& p, double* lds,
         tm = t / p.tiles_n;
         tn = t - tm * p.tiles_n;
     }
-    const int row0 = tm * T, col0 = tn * T, k_begin = ks * p.kchunk, k_end = min(p.K, k_begin + p.kchunk);
+    const int row0 = tm * T, col0 = tn * T;
+    int k_begin = ks * p.kchunk, k_end = min(p.K, k_begin + p.kchunk);
+    if (p.tri) {          // triangular operand: skip the k-range where it vanishes (whole 128-blocks, as in the generic body)
+        if (p.tri == VG_TRI_A_LOWER) k_end = min(k_end, ((row0 + T + 127) >> 7) << 7);
+        else if (p.tri == VG_TRI_A_UPPER) k_begin = max(k_begin, (row0 >> 7) << 7);
+        else if (p.tri == VG_TRI_B_UPPER) k_end = min(k_end, ((col0 + T + 127) >> 7) << 7);
+        else k_begin = max(k_begin, (col0 >> 7) << 7);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;      // 2 x 4 waves, each 32 rows x 16 columns
     const int fi = lane & 15, fk = lane >> 4;
@@ -208,7 +215,7 @@ static bool vg_deep_ok(const VgGemmP& p) {
     if (!(a_kc || a_mc) || !(b_nc || b_kc)) return false;
     const long lda = a_kc ? p.sa_m : p.sa_k, ldb = b_nc ? p.sb_k : p.sb_n;
     return (p.M % 64) == 0 && (p.N % 64) == 0 && (p.K % 32) == 0 && (p.kchunk % 32) == 0 && p.a_nslab == 1 && p.b_nslab == 1 &&
-           p.tri == VG_TRI_NONE && !p.dotw && !p.dot_out && p.C && (lda % 2) == 0 && (ldb % 2) == 0 &&
+           (p.tri == VG_TRI_NONE || p.ksplit == 1) && !p.dotw && !p.dot_out && p.C && (lda % 2) == 0 && (ldb % 2) == 0 &&
            ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0;
 }
 static bool vg_deep_batch(const VgGemmBatch* b, VgGemmBatch* out) {
