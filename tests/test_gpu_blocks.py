@@ -14,9 +14,11 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 1024, 128), (50, 37, 29), (256, 100, 1000), (1, 5, 3)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 1024, 128), (50, 37, 29), (256, 100, 1000), (1, 5, 3),
+                                   (1024, 1024, 96), (640, 1344, 160)])
 def test_gemm_layouts(engine, shape):
-    """All four operand orientations; asymmetric data so a transposed fragment map cannot hide."""
+    """All four operand orientations; asymmetric data so a transposed fragment map cannot hide.  The last two shapes are plain
+    launches of >= 128 whole tiles with k a multiple of 32: they run on the deep-stage tile (gemm.hip vg_gemm_deep_body)."""
     M, N, K = shape
     g = torch.Generator(device="cpu").manual_seed(1)
     A = torch.randn(M, K, generator=g, dtype=torch.float64).to(DEV)

@@ -19,6 +19,7 @@
 #include "gemm_body.h"
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 __global__ __launch_bounds__(256) void vg_gemm_kernel(const VgGemmBatch b) {
@@ -222,6 +223,9 @@ static bool vg_deep_batch(const VgGemmBatch* b, VgGemmBatch* out) {
     static const bool off = getenv("VGGP_NO_DEEP_GEMM") != nullptr;
     static const char* mt = getenv("VGGP_DEEP_MIN_TILES");
     const int min_tiles = mt ? atoi(mt) : 128;
+    static const bool dbg0 = getenv("VGGP_DEEP_DBG") != nullptr;
+    if (dbg0 && b->total_tiles < min_tiles && b->p[0].K >= 512)
+        fprintf(stderr, "[deep] below threshold: %d tiles, %d problems, p0 M %d N %d K %d ksplit %d\n", b->total_tiles, b->nprob, b->p[0].M, b->p[0].N, b->p[0].K, b->p[0].ksplit);
     if (off || b->total_tiles < min_tiles) return false;
     *out = *b;
     long deep_tiles = 0;
@@ -230,6 +234,14 @@ static bool vg_deep_batch(const VgGemmBatch* b, VgGemmBatch* out) {
         p.deep = vg_deep_ok(p) ? 1 : 0;
         if (p.deep) deep_tiles += (long)p.tiles_m * p.tiles_n * p.ksplit;
     }
+    static const bool dbg = getenv("VGGP_DEEP_DBG") != nullptr;
+    if (dbg && 4 * deep_tiles < 3L * out->total_tiles)
+        for (int i = 0; i < out->nprob; ++i) {
+            const VgGemmP& p = out->p[i];
+            fprintf(stderr, "[deep] NOT deep: prob %d/%d M %d N %d K %d ksplit %d kchunk %d sa (%ld,%ld) sb (%ld,%ld) aslab %d bslab %d tri %d accum %d tiles %d deep %d\n",
+                    i, out->nprob, p.M, p.N, p.K, p.ksplit, p.kchunk, p.sa_m, p.sa_k, p.sb_k, p.sb_n, p.a_nslab, p.b_nslab, p.tri, p.accum,
+                    p.tiles_m * p.tiles_n * p.ksplit, p.deep);
+        }
     return 4 * deep_tiles >= 3L * out->total_tiles;
 }
 // mixed batches: deep body for the problems flagged by the host (VgGemmP::deep), the generic 8-wave tile for the others
