@@ -77,6 +77,8 @@ extern "C" {
  * Jacobi for m <= 128.  Same results to rounding; measured slower on RBF factors and ~10 % faster on Matern factors
  * at m = 128, hence off by default. */
 #define VGGP_FLAG_BLOCK_JACOBI 2
+#define VGGP_FLAG_SCATTERED 4      /* x1[k], x2[k] are the coordinates of N = n1 = n2 scattered POINTS (not grid axes): only        */
+                                   /* vggp_elbo_step_scattered and the *_masked read-outs apply                                      */
 
 typedef struct vggp_ctx vggp_ctx;
 
@@ -197,6 +199,15 @@ int vggp_qv_cov(vggp_ctx* ctx, double* cov, void* stream);
  * gradient in (dK, dA), and d kappa(z, x)/dz = -(d kappa/d ell) ell / (z - x) for the stationary kernels.
  * Single-rank contexts only (VGGP_ESTATE otherwise). */
 int vggp_zgrad(vggp_ctx* ctx, const double* Y, double* gz1, double* gz2, void* stream);
+
+/* Collapsed ELBO and gradient for N SCATTERED observations (along-track points: the reference's _elbo(), kronecker_structure.py
+ * :249-278, receives arbitrary (x1, x2) pairs in notebooks 6 / 61 / 7 and evaluates Kuf densely, :808-823).  The context must have
+ * been planned with VGGP_FLAG_SCATTERED (x1[k], x2[k] = the coordinates of point k, n1 = n2 = N).  y [N] device, yy = sum y^2.
+ * Kuf[:, k] = a1(x1_k) (x) a2(x2_k) is a Khatri-Rao product: Sigma~ = I + rho sum_k (b1_k (x) b2_k)(b1_k (x) b2_k)^T is assembled
+ * in M-space (M = m1 m2 <= 8192) by one GEMM over the points and factored densely, as in the masked step; cost O(M^2 N + M^3).
+ * vggp_qv_masked / vggp_posterior_masked / the *_cov_masked entries read the result. */
+int vggp_elbo_step_scattered(vggp_ctx* ctx, const double* y, double yy, const double theta[5], double* elbo_out,
+                             double grad_out[5], vggp_info* info, void* stream);
 
 /* New inducing coordinates z[0..m) (host array) for dimension dim (0 or 1) of a planned context whose basis there is
  * VGGP_BASIS_POINTS, without re-planning: arena, captured graphs and the eigensolver's warm start are kept.  What an optimiser

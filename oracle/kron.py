@@ -615,3 +615,77 @@ def z_grad(st: StepState, f1: Factor, f2: Factor, Y: np.ndarray):
             tK = np.where(dzz != 0.0, dK0 / dzz, 0.0)
         out.append(-ell * ((Abar * tA).sum(1) + ((Kbar + Kbar.T) * tK).sum(1)))
     return out[0], out[1]
+
+
+# ----------------------------------------------------------------------------
+# scattered observations (along-track points: notebooks 6 / 61 / 7 feed arbitrary (x1, x2) pairs to the same _elbo):
+# Kuf[:, k] = a1(x1_k) (x) a2(x2_k) is the Khatri-Rao product of the per-dimension factors evaluated at the POINTS, Phi = Kuf Kuf^T
+# is assembled in M-space exactly as in the masked case -- the sums over observed grid points become sums over the points.
+# ----------------------------------------------------------------------------
+def elbo_step_scattered(X: np.ndarray, y: np.ndarray, f1: Factor, f2: Factor, theta) -> MaskedState:
+    """Collapsed ELBO (kronecker_structure.py:249-278) and its gradient for N scattered points X (N, 2), y (N).
+    f1.x / f2.x are ignored: the factors are evaluated at X[:, 0] and X[:, 1]."""
+    ell1, ell2, s1, s2, v = [float(t) for t in theta]
+    X = np.asarray(X, float)
+    y = np.asarray(y, float).reshape(-1)
+    N = len(y)
+    yy = float(y @ y)
+    g1 = Factor(f1.basis, f1.kind, f1.grid, X[:, 0].copy(), f1.f32_kdelta)
+    g2 = Factor(f2.basis, f2.kind, f2.grid, X[:, 1].copy(), f2.f32_kdelta)
+    d1, d2 = dim_prepare(g1, ell1, 1.0), dim_prepare(g2, ell2, 1.0)      # unit outputscale, columns = points
+    B1, V1, B2, V2 = d1.B, d1.V, d2.B, d2.V
+    m1, m2 = B1.shape[0], B2.shape[0]
+    M = m1 * m2
+    rho = s1 * s2 / v
+    kr = lambda P1, P2: (P1[:, None, :] * P2[None, :, :]).reshape(M, N)   # Khatri-Rao: row (i1, i2), column k
+    Zt = kr(B1, B2)
+    Phi = Zt @ Zt.T
+    Sig = np.eye(M) + rho * Phi
+    Lc = np.linalg.cholesky(Sig)
+    Sinv = sla.cho_solve((Lc, True), np.eye(M))
+    logdet = 2.0 * np.log(np.diag(Lc)).sum()
+    c0 = Zt @ y
+    a0 = Sinv @ c0
+    q = float(c0 @ a0)
+    A0 = a0.reshape(m1, m2)
+    nb1, nb2 = (B1 * B1).sum(0), (B2 * B2).sum(0)
+    trPhi = float(nb1 @ nb2)
+    elbo = (-0.5 * (N * math.log(2 * math.pi) + N * math.log(v) + logdet + yy / v - (s1 * s2 / v ** 2) * q)
+            - (N * s1 * s2 - s1 * s2 * trPhi) / (2 * v))
+    trSP = (M - np.trace(Sinv)) / rho
+    aPa = (q - float(a0 @ a0)) / rho
+    common = -0.5 * (rho * trSP - (s1 * s2 / v ** 2) * q + (s1 * s2 / v ** 2) * rho * aPa)
+    g_s1 = common / s1 - (N * s2 - s2 * trPhi) / (2 * v)
+    g_s2 = common / s2 - (N * s1 - s1 * trPhi) / (2 * v)
+    g_v = (-0.5 * (N / v - (rho / v) * trSP - yy / v ** 2 + 2 * s1 * s2 * q / v ** 3 - (s1 * s2 * rho / v ** 3) * aPa)
+           + (N * s1 * s2 - s1 * s2 * trPhi) / (2 * v ** 2))
+    S4 = Sinv.reshape(m1, m2, m1, m2)
+    zb = np.einsum("ik,ij,jk->k", B1, A0, B2)                          # b1_k^T A0 b2_k
+
+    def ell_grad(dim):
+        if dim == 1:
+            Phip = Zt @ kr(V1, B2).T                                     # sum_k (b1 (x) b2)(v1 (x) b2)^T
+            Mk, m_other = d1.Mk, m2
+            PTS = np.einsum("ajbj->ab", S4)
+            C1 = kr(V1, B2) @ y
+            quadMk = np.einsum("ik,ij,kj->", Mk, A0, A0)
+            Z = float(np.einsum("ik,ij,jk->k", V1, A0, B2) @ zb)
+            tr1 = float(((V1 * B1).sum(0)) @ nb2)
+            PT = (B1 * nb2[None, :]) @ B1.T
+        else:
+            Phip = Zt @ kr(B1, V2).T
+            Mk, m_other = d2.Mk, m1
+            PTS = np.einsum("iaib->ab", S4)
+            C1 = kr(B1, V2) @ y
+            quadMk = np.einsum("ik,ji,jk->", Mk, A0, A0)
+            Z = float(np.einsum("ik,ij,jk->k", B1, A0, V2) @ zb)
+            tr1 = float(((V2 * B2).sum(0)) @ nb1)
+            PT = (B2 * nb1[None, :]) @ B2.T
+        ld = float((Mk * PTS.T).sum()) - m_other * np.trace(Mk) + 2 * rho * float((Sinv * Phip).sum())
+        quad = 2 * float(a0 @ C1) - quadMk - 2 * rho * Z
+        return -0.5 * (ld - (s1 * s2 / v ** 2) * quad) + (s1 * s2 / (2 * v)) * (2 * tr1 - float((Mk * PT.T).sum()))
+
+    st = MaskedState(theta=np.asarray(theta, float), d1=d1, d2=d2, Sinv=Sinv, A0=A0, N=N)
+    st.elbo = float(elbo)
+    st.grad = np.array([ell_grad(1), ell_grad(2), g_s1, g_s2, g_v])
+    return st

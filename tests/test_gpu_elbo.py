@@ -583,3 +583,34 @@ def test_set_inducing_keeps_plan_and_tracks_the_oracle(engine, kind):
     assert engine.plan_token == token
     with pytest.raises(Exception):
         engine.set_inducing(0, z1[:-1])
+
+
+@pytest.mark.parametrize("basis,kind,g1,g2,N", [
+    ("b0", "matern12", np.linspace(0, 1, 9), np.linspace(0, 1, 7), 300),
+    ("points", "matern32", np.linspace(0, 1, 12), np.linspace(0.05, 0.95, 10), 1500),
+    ("points", "rbf", np.linspace(0, 1, 16), np.linspace(0, 1, 16), 5000),
+    ("b0", "matern12", np.linspace(0, 1, 33), np.linspace(0, 1, 33), 20000)])
+def test_scattered_step_vs_oracle(engine, basis, kind, g1, g2, N):
+    """vggp_elbo_step_scattered: N points that form no grid (the reference's _elbo() on along-track data, kronecker_structure.py
+    :249-278 with _Kuf(x) :808-823 for arbitrary x) against oracle/kron.py elbo_step_scattered, which equals the literal dense
+    restatement's autograd to 1e-14 (tests/test_oracle.py); q(v) and the posterior read-outs through the masked entries."""
+    rng = np.random.default_rng(11)
+    X = rng.uniform(0, 1, (N, 2))
+    y = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.1 * rng.standard_normal(N)
+    th = np.array([0.3, 0.25, 1.2, 0.8, 0.05])
+    f1, f2 = Kr.Factor(basis, kind, g1, np.zeros(1)), Kr.Factor(basis, kind, g2, np.zeros(1))
+    ref = Kr.elbo_step_scattered(X, y, f1, f2, th)
+    engine.plan(kind, basis, g1, X[:, 0].copy(), kind, basis, g2, X[:, 1].copy(), scattered=True)
+    yd = torch.tensor(y, device=DEV)
+    elbo, grad, info = engine.elbo_step_scattered(yd, float(y @ y), th)
+    assert abs(elbo - ref.elbo) <= RTOL * abs(ref.elbo)
+    assert rel(grad, ref.grad) < RTOL
+    mean, var = engine.qv_masked()
+    rm, rv = Kr.q_v_masked(ref, f1, f2)
+    assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-6
+    xs = rng.uniform(0, 1, (40, 2))
+    pm, pv = engine.posterior_masked(torch.tensor(xs))
+    qm, qv = Kr.posterior_masked(ref, f1, f2, xs)
+    assert rel(pm.cpu().numpy(), qm) < 1e-6 and rel(pv.cpu().numpy(), qv) < 1e-6
+    with pytest.raises(Exception):
+        engine.elbo_step(torch.zeros(N, N, dtype=torch.float64, device=DEV)[:2], 0.0, th)      # grid step on a scattered plan

@@ -132,9 +132,10 @@ def test_initialisers_and_errors(engine):
     assert model.kernel_1.base_kernel.lengthscale.item() == ell_before       # the reference's getter quirk
     assert abs(model.likelihood.noise.item() - yt.var().item() / 100.0) < 1e-9
     assert np.isfinite(model._elbo().item())
-    with pytest.raises(ValueError):      # general scattered inputs (no underlying grid) are out of scope
-        Xr = torch.tensor(np.random.default_rng(0).uniform(size=(200, 2)))
-        Matern12GriddedGP(Xr, yt[:200] if len(yt) >= 200 else torch.zeros(200), 6, (0, 1), (0, 1), engine=engine)
+    # general scattered inputs (no underlying grid): routed to the scattered step (test_scattered_inputs_model_matches_dense_oracle)
+    Xr = torch.tensor(np.random.default_rng(0).uniform(size=(200, 2)))
+    sc = Matern12GriddedGP(Xr, yt[:200] if len(yt) >= 200 else torch.zeros(200), 6, (0, 1), (0, 1), engine=engine)
+    assert sc._scattered and np.isfinite(sc._elbo().item())
     with pytest.raises(ValueError):      # duplicated points
         Matern12GriddedGP(torch.cat([Xt[:-3], Xt[:1]]), torch.cat([yt[:-3], yt[:1]]), 6, (0, 1), (0, 1), engine=engine)
 
@@ -439,3 +440,46 @@ def test_univariate_svgp_trainable_inducing_points(engine):
     ed.backward()
     assert abs(e.item() - ed.item()) <= 1e-6 * abs(ed.item())
     assert rel(model.Z.grad.numpy().reshape(-1), dm.grid.grad.numpy()) < 1e-5
+
+
+def test_scattered_inputs_model_matches_dense_oracle(engine):
+    """X that is no (masked) grid at all -- along-track style points, what the reference's notebooks 6 / 61 / 7 feed to the same
+    classes: the model routes to vggp_elbo_step_scattered; ELBO, raw gradients, q_v and posterior against the literal dense
+    restatement on the same points."""
+    from variational_gridded_gaussian_processes_amd.models import Matern12GriddedGP, Matern32SVGP
+    rng = np.random.default_rng(4)
+    N, nk = 400, 8
+    t = np.linspace(0, 1, N)
+    X = np.stack([(0.5 + 0.45 * np.sin(9 * t) + 0.01 * rng.standard_normal(N)).clip(0, 1),
+                  (t + 0.02 * rng.standard_normal(N)).clip(0, 1)], axis=1)          # a wiggly track
+    y = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.05 * rng.standard_normal(N)
+    model = Matern12GriddedGP(torch.tensor(X), torch.tensor(y), nk, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    assert model._scattered
+    dm = D.DenseKron(X, y, "b0", "matern12", torch.linspace(0, 1, nk), torch.linspace(0, 1, nk))
+    e = model._elbo()
+    e.backward()
+    ed, gd = dm.elbo_and_grad()
+    assert abs(e.item() - ed.item()) <= 1e-6 * abs(ed.item())
+    got = np.array([model.kernel_1.base_kernel.raw_lengthscale.grad.item(), model.kernel_2.base_kernel.raw_lengthscale.grad.item(),
+                    model.kernel_1.raw_outputscale.grad.item(), model.kernel_2.raw_outputscale.grad.item(),
+                    model.likelihood.raw_noise.grad.item()])
+    assert rel(got, gd.numpy()) < 1e-5
+    qv, dq = model.q_v(), dm.q_v()
+    assert rel(qv.mean.numpy(), dq.mean.detach().numpy()) < 1e-5
+    assert rel(qv.variance.numpy(), torch.diagonal(dq.covariance_matrix).detach().numpy()) < 1e-5
+    xs = rng.uniform(0, 1, (25, 2))
+    p, dp = model.posterior(torch.tensor(xs)), dm.posterior(torch.tensor(xs))
+    assert rel(p.mean.numpy(), dp.mean.detach().numpy()) < 1e-5
+    assert rel(p.variance.numpy(), torch.diagonal(dp.covariance_matrix).detach().numpy()) < 1e-5
+    # an Adam loop on scattered data (points basis, fixed Z)
+    Z = torch.tensor(np.stack([np.linspace(0, 1, 7), np.linspace(0, 1, 7)], axis=1))
+    sv = Matern32SVGP(torch.tensor(X), torch.tensor(y), Z, engine=engine, train_z=False).to(torch.float64)
+    opt = torch.optim.Adam(sv.parameters(), lr=0.05)
+    first = None
+    for it in range(8):
+        opt.zero_grad()
+        loss = -sv._elbo()
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+    assert loss.item() < first

@@ -15,6 +15,7 @@ KIND = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 NSTAGE = 20
 FLAG_B0_F32_KDELTA = 1
 FLAG_BLOCK_JACOBI = 2
+FLAG_SCATTERED = 4
 BASIS = {"points": 0, "b0": 1, "one": 2, "vff": 3, "b1": 4}
 
 
@@ -57,6 +58,7 @@ SYMBOLS = {
     "vggp_elbo_partials": (_I, [_P, _P, C.POINTER(_D), _P, _P]),
     "vggp_elbo_finish": (_I, [_P, _P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
     "vggp_elbo_step_masked": (_I, [_P, _P, _P, _D, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
+    "vggp_elbo_step_scattered": (_I, [_P, _P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
     "vggp_qv_masked": (_I, [_P, _P, _P, _P]),
     "vggp_qv": (_I, [_P, _P, _P, _P]),
     "vggp_qv_cov": (_I, [_P, _P, _P]),

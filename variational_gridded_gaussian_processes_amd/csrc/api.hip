@@ -296,7 +296,11 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     VG_REQUIRE(desc->x1 && desc->x2, "vggp_plan: null coordinate arrays");
     VG_REQUIRE((desc->basis1 == VGGP_BASIS_ONE || desc->grid1) && (desc->basis2 == VGGP_BASIS_ONE || desc->grid2),
                "vggp_plan: null grid arrays");
-    VG_REQUIRE(desc->n_total >= desc->n1 * desc->n2, "vggp_plan: n_total smaller than the local grid");
+    if (desc->flags & VGGP_FLAG_SCATTERED)
+        VG_REQUIRE(desc->n1 == desc->n2 && desc->basis1 != VGGP_BASIS_ONE && desc->basis2 != VGGP_BASIS_ONE,
+                   "vggp_plan: scattered points need n1 == n2 (one coordinate pair per point) and two real dimensions");
+    else
+        VG_REQUIRE(desc->n_total >= desc->n1 * desc->n2, "vggp_plan: n_total smaller than the local grid");
     VG_REQUIRE(desc->n1 < (1L << 24) && desc->n2 < (1L << 24), "vggp_plan: grid axis too long");
     c->planned = false;
     graphs_clear(c);
@@ -514,6 +518,15 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     }
     VG_MARK(2);
 
+    if (!Y) {          // factors only (scattered step, masked.hip): B|V, X are done; Mk = X Linv0^T and nothing of the grid path
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.X, d.m, 1, d.Linv0, 1, d.m, d.Mk, d.m, d.m, d.m, d.m);
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        return VGGP_OK;
+    }
     // 4./5. (side stream in the fused step: overlaps the Gram products and the whole eigensolver chain, which need only G, H)
     //    S = [B2;V2] Y (split-K slabs): the only pass over Y; then [C;C1] = [B1;V1] S_B, C2 = B1 S_V (S slabs summed on
     //    load; split-K over n1).
@@ -1110,6 +1123,7 @@ extern "C" int vggp_elbo_step(vggp_ctx* c, const double* Y, double yy_total, con
 static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
                           double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step: context not planned"); return VGGP_ESTATE; }
+    if (c->desc.flags & VGGP_FLAG_SCATTERED) { vg_set_error("vggp_elbo_step: the context was planned for scattered points (use vggp_elbo_step_scattered)"); return VGGP_ESTATE; }
     VG_REQUIRE(Y && theta && elbo_out && grad_out, "vggp_elbo_step: null argument");
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;

@@ -195,6 +195,7 @@ __global__ void vgm_scale_rho_kernel(double* x, long n, const double* theta, int
 struct VgMasked {
     long M = 0, n1 = 0, n2 = 0;
     int m1 = 0, m2 = 0, nblk = 0;
+    bool scattered = false;        // n1 == n2 == number of points: the [n2][n1] grid buffers shrink to per-point vectors
     double *Sg, *Lg, *Xg, *Sinv, *R, *Phip, *DI, *Tmp;          // M x M (Phip: two of them; Tmp: 128 x M)
     double *PP1, *PP1v, *PP2, *PP2v, *T, *Tv;
     double *UB, *UV, *Zb, *Zv1, *Zv2, *B1s, *B2s;
@@ -219,8 +220,9 @@ static void vgm_layout(VgMasked& w, char* base, size_t& off) {
     w.Sg = take(MM); w.Lg = take(MM); w.Xg = take(MM); w.Sinv = take(MM); w.R = take(MM); w.Phip = take(2 * MM);
     w.DI = take((size_t)w.nblk * VG_MB * VG_MB); w.Tmp = take((size_t)VG_MB * M);
     w.PP1 = take(m1 * m1 * n1); w.PP1v = take(m1 * m1 * n1); w.PP2 = take(m2 * m2 * n2); w.PP2v = take(m2 * m2 * n2);
-    w.T = take(n1 * m2 * m2); w.Tv = take(n1 * m2 * m2);
-    w.UB = take(m1 * n2); w.UV = take(m1 * n2); w.Zb = take(n1 * n2); w.Zv1 = take(n1 * n2); w.Zv2 = take(n1 * n2);
+    const size_t grid = w.scattered ? n1 : n1 * n2;            // scattered: zb, zv1, zv2 are per-point vectors
+    w.T = take(w.scattered ? 256 : n1 * m2 * m2); w.Tv = take(w.scattered ? 256 : n1 * m2 * m2);
+    w.UB = take(m1 * n2); w.UV = take(m1 * n2); w.Zb = take(grid); w.Zv1 = take(grid); w.Zv2 = take(grid);
     w.B1s = take(m1 * n1); w.B2s = take(m2 * n2);
     w.nb1 = take(n1); w.nb2 = take(n2); w.hv1 = take(n1); w.hv2 = take(n2); w.wn1 = take(n2);
     w.mpay = take(2 * m2 * m2 + 3 * M + n1 + 3 * MM);
@@ -238,9 +240,10 @@ static int vgm_prepare(vggp_ctx* c) {
     VgMasked* w = reinterpret_cast<VgMasked*>(c->masked);
     if (!w) { w = new VgMasked(); c->masked = w; }
     const long m1 = c->desc.m1, m2 = c->desc.m2;
-    if (w->mem && w->M == m1 * m2 && w->n1 == c->desc.n1 && w->n2 == c->desc.n2 && w->m1 == m1) return VGGP_OK;
+    const bool sc = (c->desc.flags & VGGP_FLAG_SCATTERED) != 0;
+    if (w->mem && w->M == m1 * m2 && w->n1 == c->desc.n1 && w->n2 == c->desc.n2 && w->m1 == m1 && w->scattered == sc) return VGGP_OK;
     if (w->mem) { VG_HIP(hipFree(w->mem)); w->mem = nullptr; }
-    w->M = m1 * m2; w->m1 = (int)m1; w->m2 = (int)m2; w->n1 = c->desc.n1; w->n2 = c->desc.n2;
+    w->M = m1 * m2; w->m1 = (int)m1; w->m2 = (int)m2; w->n1 = c->desc.n1; w->n2 = c->desc.n2; w->scattered = sc;
     w->nblk = (int)((w->M + VG_MB - 1) / VG_MB);
     size_t off = 0;
     vgm_layout(*w, nullptr, off);
@@ -320,6 +323,7 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step_masked: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(Ym && W && theta && elbo_out && grad_out, "vggp_elbo_step_masked: null argument");
     c->have_masked = false;          // a failed step must not leave an earlier step's state readable (qv_masked / posterior_masked)
+    VG_REQUIRE(!(c->desc.flags & VGGP_FLAG_SCATTERED), "vggp_elbo_step_masked: the context was planned for scattered points");
     const long m1 = c->desc.m1, m2 = c->desc.m2, n1 = c->desc.n1, n2 = c->desc.n2, M = m1 * m2;
     VG_REQUIRE(M <= 8192, "vggp_elbo_step_masked: M = m1*m2 = %ld too large for the dense masked solver (<= 8192)", M);
     VG_REQUIRE(m1 * m1 * n1 < (1L << 31) && m2 * m2 * n2 < (1L << 31) && M * M < (1L << 31) * 4, "masked problem too large");
@@ -444,6 +448,130 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
         info->status = status; info->polished = 0;
     }
     if (status) { vg_set_error("masked step: a factor is not positive definite"); return VGGP_ENOTPD; }
+    c->have_masked = true;
+    return VGGP_OK;
+}
+
+// ---- scattered observations ----------------------------------------------------------------------------------------------
+// N points (x1_k, x2_k, y_k) that form no grid (satellite tracks: the reference's notebooks 6 / 61 / 7 feed them to the same
+// _elbo(), kronecker_structure.py:249-278, whose _Kuf(x) :808-823 takes any x).  Kuf[:, k] = a1(x1_k) (x) a2(x2_k): with the
+// per-dimension factors evaluated AT THE POINTS (B_d is m_d x N), Phi~0 = sum_k (b1_k (x) b2_k)(b1_k (x) b2_k)^T is a single
+// GEMM over the points between the row-pair products, R[(i1,k1),(i2,k2)] = sum_k (B1[i1,k] B1[k1,k]) (B2[i2,k] B2[k2,k]);
+// everything after the assembly -- dense factorisation of Sigma~ = I + rho Phi~0, a0, the gradient's scalars, the final
+// combination, the read-outs -- is the masked step's, with sums over observed grid points replaced by sums over the points.
+// Specification: oracle/kron.py elbo_step_scattered (== the literal dense restatement to 1e-14).  Single rank.
+extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy, const double theta[5], double* elbo_out,
+                                        double grad_out[5], vggp_info* info, void* stream) {
+    if (!c || !c->planned) { vg_set_error("vggp_elbo_step_scattered: context not planned"); return VGGP_ESTATE; }
+    VG_REQUIRE(y && theta && elbo_out && grad_out, "vggp_elbo_step_scattered: null argument");
+    VG_REQUIRE(c->desc.flags & VGGP_FLAG_SCATTERED, "vggp_elbo_step_scattered: plan the context with VGGP_FLAG_SCATTERED");
+    VG_REQUIRE(!(c->n_ranks > 1 || c->comm || c->cb), "vggp_elbo_step_scattered: row-sharded contexts are not supported");
+    c->have_masked = false;
+    const long m1 = c->desc.m1, m2 = c->desc.m2, N = c->desc.n1, M = m1 * m2;
+    VG_REQUIRE(M <= 8192, "vggp_elbo_step_scattered: M = m1*m2 = %ld too large for the dense solver (<= 8192)", M);
+    VG_REQUIRE(m1 * m1 * N < (1L << 31) && m2 * m2 * N < (1L << 31) && M * M < (1L << 31) * 4, "scattered problem too large");
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    for (int i = 0; i < 5; ++i) {
+        VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
+        c->h_theta[i] = theta[i];
+    }
+    int rc = vgm_prepare(c);
+    if (rc) return rc;
+    VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
+    if ((rc = vg_partials_enqueue(c, nullptr, nullptr, st))) return rc;          // factors at the points: B|V, Mk (unit outputscale)
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const double *B1 = d1.BV, *V1 = d1.BV + m1 * N, *B2 = d2.BV, *V2 = d2.BV + m2 * N;
+    double *C0 = w.mpay + 2 * m2 * m2, *C1 = C0 + M, *C2 = C1 + M;
+    // projections: C0 = B1 diag(y) B2^T, C1 = V1 diag(y) B2^T, C2 = B1 diag(y) V2^T   (m1 x m2, K = N)
+    VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * N, st, B1, y, (int)m1, N, w.B1s);
+    VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * N, st, V1, y, (int)m1, N, w.UV);           // (UV is free until the a0 stage)
+    if ((rc = gemm1(w.B1s, N, 1, B2, 1, N, C0, (int)m2, (int)m1, (int)m2, (int)N, st))) return rc;
+    if ((rc = gemm1(w.UV, N, 1, B2, 1, N, C1, (int)m2, (int)m1, (int)m2, (int)N, st))) return rc;
+    if ((rc = gemm1(w.B1s, N, 1, V2, 1, N, C2, (int)m2, (int)m1, (int)m2, (int)N, st))) return rc;
+    // per-point statistics
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B1, B1, (int)m1, N, w.nb1);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B2, B2, (int)m2, N, w.nb2);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, V1, B1, (int)m1, N, w.hv1);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, V2, B2, (int)m2, N, w.hv2);
+    // assembly: one GEMM over the points per matrix
+    VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * N, st, B2, B2, (int)m2, (int)m2, N, w.PP2);
+    VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * N, st, B2, V2, (int)m2, (int)m2, N, w.PP2v);
+    VGM_LAUNCH1D(vgm_pairprod_kernel, m1 * m1 * N, st, B1, B1, (int)m1, (int)m1, N, w.PP1);
+    VGM_LAUNCH1D(vgm_pairprod_kernel, m1 * m1 * N, st, B1, V1, (int)m1, (int)m1, N, w.PP1v);
+    VG_HIP(hipGetLastError());
+    if ((rc = gemm1(w.PP1, N, 1, w.PP2, 1, N, w.R3, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)N, st))) return rc;
+    if ((rc = gemm1(w.PP1v, N, 1, w.PP2, 1, N, w.R3 + M * M, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)N, st))) return rc;
+    if ((rc = gemm1(w.PP1, N, 1, w.PP2v, 1, N, w.R3 + 2 * M * M, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)N, st))) return rc;
+    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3, (int)m1, (int)m2, c->theta, 1, w.Sg);
+    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3 + M * M, (int)m1, (int)m2, c->theta, 0, w.Phip);
+    VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3 + 2 * M * M, (int)m1, (int)m2, c->theta, 0, w.Phip + M * M);
+    if ((rc = dense_chol_inverse(c, w, st))) return rc;
+    if ((rc = gemm1(w.Sinv, M, 1, C0, 1, 1, w.a0, 1, (int)M, 1, (int)M, st))) return rc;
+    if ((rc = gemm1(d1.Mk, m1, 1, w.a0, m2, 1, w.MkA1, (int)m2, (int)m1, (int)m2, (int)m1, st))) return rc;
+    if ((rc = gemm1(w.a0, m2, 1, d2.Mk, m2, 1, w.MkA2, (int)m2, (int)m1, (int)m2, (int)m2, st))) return rc;
+    // UB = A0 B2, UV = A0 V2 (m1 x N); zb_k = b1_k^T A0 b2_k, zv1_k = v1_k^T A0 b2_k, zv2_k = b1_k^T A0 v2_k
+    if ((rc = gemm1(w.a0, m2, 1, B2, N, 1, w.UB, (int)N, (int)m1, (int)N, (int)m2, st))) return rc;
+    if ((rc = gemm1(w.a0, m2, 1, V2, N, 1, w.UV, (int)N, (int)m1, (int)N, (int)m2, st))) return rc;
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B1, w.UB, (int)m1, N, w.Zb);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, V1, w.UB, (int)m1, N, w.Zv1);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B1, w.UV, (int)m1, N, w.Zv2);
+    // PT_d = B_d diag(|b_other|^2) B_d^T, partial traces of Sinv
+    VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * N, st, B1, w.nb2, (int)m1, N, w.B1s);
+    VGM_LAUNCH1D(vgm_scalecols_kernel, m2 * N, st, B2, w.nb1, (int)m2, N, w.B2s);
+    if ((rc = gemm1(w.B1s, N, 1, B1, 1, N, w.PT1, (int)m1, (int)m1, (int)m1, (int)N, st))) return rc;
+    if ((rc = gemm1(w.B2s, N, 1, B2, 1, N, w.PT2, (int)m2, (int)m2, (int)m2, (int)N, st))) return rc;
+    VGM_LAUNCH1D(vgm_ptrace_kernel, m1 * m1, st, w.Sinv, (int)m1, (int)m2, 1, w.PTS1);
+    VGM_LAUNCH1D(vgm_ptrace_kernel, m2 * m2, st, w.Sinv, (int)m1, (int)m2, 2, w.PTS2);
+    VgmRedArgs ra;
+    ra.njobs = RJ_COUNT;
+    ra.partial = w.partial;
+    auto job = [&](int k, const double* a, const double* b, long n, long sa, long sb, int op) {
+        ra.job[k] = VgmRedJob{a, b, nullptr, n, sa, sb, op};
+    };
+    job(RJ_LOGDET, w.Lg, nullptr, M, M + 1, 0, 1);
+    job(RJ_Q, C0, w.a0, M, 1, 1, 0);
+    job(RJ_AA, w.a0, w.a0, M, 1, 1, 0);
+    job(RJ_TRS, w.Sinv, nullptr, M, M + 1, 0, 2);
+    job(RJ_TRPHI, w.nb1, w.nb2, N, 1, 1, 0);
+    job(RJ_MK1PTS, d1.Mk, w.PTS1, m1 * m1, 1, 1, 0);
+    job(RJ_TRMK1, d1.Mk, nullptr, m1, m1 + 1, 0, 2);
+    job(RJ_SPHI1, w.Sinv, w.Phip, M * M, 1, 1, 0);
+    job(RJ_AC1, w.a0, C1, M, 1, 1, 0);
+    job(RJ_MKA1, w.MkA1, w.a0, M, 1, 1, 0);
+    job(RJ_Z1, w.Zb, w.Zv1, N, 1, 1, 0);
+    job(RJ_HV1, w.hv1, w.nb2, N, 1, 1, 0);
+    job(RJ_MK1PT, d1.Mk, w.PT1, m1 * m1, 1, 1, 0);
+    job(RJ_MK2PTS, d2.Mk, w.PTS2, m2 * m2, 1, 1, 0);
+    job(RJ_TRMK2, d2.Mk, nullptr, m2, m2 + 1, 0, 2);
+    job(RJ_SPHI2, w.Sinv, w.Phip + M * M, M * M, 1, 1, 0);
+    job(RJ_AC2, w.a0, C2, M, 1, 1, 0);
+    job(RJ_MKA2, w.MkA2, w.a0, M, 1, 1, 0);
+    job(RJ_Z2, w.Zb, w.Zv2, N, 1, 1, 0);
+    job(RJ_HV2, w.hv2, w.nb1, N, 1, 1, 0);
+    job(RJ_MK2PT, d2.Mk, w.PT2, m2 * m2, 1, 1, 0);
+    hipLaunchKernelGGL(vgm_red_kernel, dim3(VG_MD_NPART, RJ_COUNT), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(vgm_sum_kernel, dim3(1), dim3(64), 0, st, w.partial, w.scal, 0u, 1);
+    VgmFinalArgs fa{c->theta, w.scal, w.out, (double)N, yy, (int)m1, (int)m2};
+    hipLaunchKernelGGL(vgm_final_kernel, dim3(1), dim3(64), 0, st, fa);
+    VG_HIP(hipGetLastError());
+    VG_HIP(hipMemcpyAsync(c->h_out->out, w.out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < 2; ++k) {
+        VG_HIP(hipMemcpyAsync(&c->h_out->jitter[k], c->d[k].jitter, sizeof(double), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipMemcpyAsync(&c->h_out->status[k], c->d[k].status, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    VG_HIP(hipMemcpyAsync(&c->h_out->counters[1][3], w.cholstatus, sizeof(int), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    const int hs = c->h_out->counters[1][3];
+    *elbo_out = c->h_out->out[0];
+    for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
+    const int status = c->h_out->status[0] ? c->h_out->status[0] : (c->h_out->status[1] ? c->h_out->status[1] : hs);
+    if (info) {
+        info->jitter1 = c->h_out->jitter[0]; info->jitter2 = c->h_out->jitter[1];
+        info->sweeps1 = info->sweeps2 = info->rounds1 = info->rounds2 = 0;
+        info->status = status; info->polished = 0;
+    }
+    if (status) { vg_set_error("scattered step: a factor is not positive definite"); return VGGP_ENOTPD; }
     c->have_masked = true;
     return VGGP_OK;
 }

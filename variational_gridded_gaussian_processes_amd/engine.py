@@ -113,7 +113,7 @@ class Engine:
     # -- planning -------------------------------------------------------------------------------
     def plan(self, kind1: str, basis1: str, grid1, x1, kind2: str, basis2: str, grid2, x2,
              n_total: Optional[int] = None, warm_start: bool = False, b0_f32_kdelta: bool = False,
-             block_jacobi: bool = False) -> None:
+             block_jacobi: bool = False, scattered: bool = False) -> None:
         """grid_d: mesh (m+1 knots, basis 'b0'), inducing coordinates (m, 'points'), knot mesh (m, 'b1') or
         [a, b, omega_0 .. omega_M] (m = 2M + 1, 'vff'); x_d: the n_d unique (local) observation coordinates along d."""
         x1, x2 = _dvec(x1), _dvec(x2)
@@ -127,7 +127,13 @@ class Engine:
         d.x1, d.x2 = x1.ctypes.data, x2.ctypes.data
         d.grid1, d.grid2 = g1.ctypes.data, g2.ctypes.data
         d.warm_start = 1 if warm_start else 0
-        d.flags = (_lib.FLAG_B0_F32_KDELTA if b0_f32_kdelta else 0) | (_lib.FLAG_BLOCK_JACOBI if block_jacobi else 0)
+        d.flags = (_lib.FLAG_B0_F32_KDELTA if b0_f32_kdelta else 0) | (_lib.FLAG_BLOCK_JACOBI if block_jacobi else 0) | \
+                  (_lib.FLAG_SCATTERED if scattered else 0)
+        if scattered:          # x1[k], x2[k]: the coordinates of point k (no grid)
+            if len(x1) != len(x2):
+                raise ValueError("scattered plan: x1 and x2 must hold one coordinate pair per point")
+            d.n_total = len(x1)
+        self.scattered = bool(scattered)
         with torch.cuda.device(self.device):
             check(self.lib.vggp_plan(self._h, C.byref(d)))
         self.m1, self.m2, self.n1, self.n2 = m1, m2, len(x1), len(x2)
@@ -165,6 +171,19 @@ class Engine:
         info = Info()
         check(self.lib.vggp_elbo_step_masked(self._h, _ptr(Ym), _ptr(W), float(n_obs), float(yy_obs), th, C.byref(elbo),
                                              grad, C.byref(info), _stream(self.device)))
+        return elbo.value, np.array(list(grad)), self._info(info)
+
+    def elbo_step_scattered(self, y: torch.Tensor, yy: float, theta: Sequence[float]):
+        """N scattered points (plan(..., scattered=True) with their coordinate pairs): y [N] float64 GPU tensor, yy = sum y^2;
+        -> (elbo, grad[5], info).  qv_masked / posterior_masked / the *_cov_masked read-outs apply afterwards."""
+        if not (y.is_cuda and y.dtype == torch.float64 and y.is_contiguous() and y.numel() == self.n1):
+            raise TypeError("y must be a contiguous float64 GPU tensor with one value per planned point")
+        th = (C.c_double * 5)(*[float(t) for t in theta])
+        elbo = C.c_double()
+        grad = (C.c_double * 5)()
+        info = Info()
+        check(self.lib.vggp_elbo_step_scattered(self._h, _ptr(y), float(yy), th, C.byref(elbo), grad, C.byref(info),
+                                                _stream(self.device)))
         return elbo.value, np.array(list(grad)), self._info(info)
 
     def qv_masked(self) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -175,8 +175,9 @@ def _detect_grid(X: torch.Tensor):
     x1, i = np.unique(Xn[:, 0], return_inverse=True)
     x2, j = np.unique(Xn[:, 1], return_inverse=True)
     if len(x1) * len(x2) > 16 * N:
-        raise ValueError("X is neither a full grid (gen_2d layout) nor a masked grid: its unique coordinates span "
-                         f"{len(x1)} x {len(x2)} grid points for {N} observations (general scattered inputs are out of scope)")
+        # general scattered points (along-track data): no grid at all -- the per-point coordinates go to the engine as they are
+        # (vggp_elbo_step_scattered: Khatri-Rao assembly in M-space)
+        return Xn[:, 0].copy(), Xn[:, 1].copy(), "scattered", None
     flat = j.astype(np.int64) * len(x1) + i.astype(np.int64)
     W = np.zeros(len(x1) * len(x2))
     W[flat] = 1.0
@@ -205,8 +206,12 @@ class KroneckerStructure(torch.nn.Module):
         self._x1, self._x2, W, flat = _detect_grid(X)
         n2, n1 = len(self._x2), len(self._x1)
         yd = torch.as_tensor(y, dtype=torch.float64).reshape(-1).to(self._engine.device)
-        self._masked = W is not None
-        if self._masked:                 # masked grid: scatter the observations onto the grid (zeros elsewhere)
+        self._scattered = isinstance(W, str)
+        self._masked = W is not None     # (read-outs of the scattered mode are the masked ones: dense M-space state)
+        if self._scattered:              # scattered points: y stays a vector, one coordinate pair per point
+            self._Y = yd.contiguous()
+            self._nobs = float(yd.numel())
+        elif self._masked:               # masked grid: scatter the observations onto the grid (zeros elsewhere)
             self._W = torch.as_tensor(W, device=self._engine.device)
             self._Y = torch.zeros(n2 * n1, dtype=torch.float64, device=self._engine.device)
             self._Y[torch.as_tensor(flat, device=self._engine.device)] = yd
@@ -214,7 +219,7 @@ class KroneckerStructure(torch.nn.Module):
             self._nobs = float(W.sum())
         else:
             self._Y = yd.reshape(n2, n1).contiguous()
-        self._yy = self._engine.sumsq(self._Y)
+        self._yy = float((yd * yd).sum().item()) if self._scattered else self._engine.sumsq(self._Y)
 
     # subclasses provide (basis, grid_1, grid_2)
     def _basis(self) -> Tuple[str, np.ndarray, np.ndarray]:
@@ -240,7 +245,7 @@ class KroneckerStructure(torch.nn.Module):
             self._plan_key = key
         elif not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
             self._engine.plan(self.kind, basis, g1, self._x1, self.kind, basis, g2, self._x2, warm_start=self._warm,
-                              b0_f32_kdelta=self._f32_mesh())
+                              b0_f32_kdelta=self._f32_mesh(), scattered=self._scattered)
             self._planned = True
             self._plan_token, self._plan_key = self._engine.plan_token, key
 
@@ -252,6 +257,8 @@ class KroneckerStructure(torch.nn.Module):
 
     def _engine_step(self, theta):
         self._plan()
+        if self._scattered:
+            return self._engine.elbo_step_scattered(self._Y, self._yy, theta)
         if self._masked:
             return self._engine.elbo_step_masked(self._Y, self._W, self._nobs, self._yy, theta)
         return self._engine.elbo_step(self._Y, self._yy, theta)
@@ -578,7 +585,7 @@ class Matern12SVGP(KroneckerStructure):
 
     def __init__(self, X, y, Z: torch.Tensor, train_z: bool = True, **kw):
         super().__init__(X, y, **kw)
-        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=bool(train_z) and not self._masked)
+        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=bool(train_z) and not self._masked)      # (masked / scattered steps: fixed Z)
 
     def _elbo(self) -> torch.Tensor:
         return _ElboFunction.apply(self._theta(), self, self.Z)
