@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   cold_ms_per_step  the same loop with the eigensolver's warm start off
   m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
   svgp_train_z      ms per optimiser iteration of an SVGP whose inducing points are trained (step + Z-gradient + in-place move)
+  scattered         vggp_elbo_step_scattered: ms per step for 100 000 points that form no grid (B0 cells, m_d = 32)
   slab_1024x4096    the per-rank shape of BASELINE configs[3]: ms per step, and the projection kernel's MFMA fraction at that size
   kron_solve        BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
   factor_build      HBM-write rate of the factor kernel at m = n = 8192
@@ -357,6 +358,7 @@ def main():
                                                     warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
             out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
             out["svgp_train_z"] = trainz_bench(eng, Y, yy, x1, x2, m)
+            out["scattered"] = scattered_bench(eng)
             out["kron_solve"] = kron_solve_bench(eng, 1024)
             out["factor_build"] = factor_build_bench(eng)
         if not args.no_cpu and world == 1 and not args.masked:
@@ -446,6 +448,38 @@ def trainz_bench(eng, Y, yy, x1, x2, m, kind="matern32", steps=60, warmup=15):
     torch.cuda.synchronize()
     return {"kind": kind, "ms_per_iteration": (time.perf_counter() - t0) / steps * 1e3, "elbo_last": e,
             "what": "elbo_step + zgrad + set_inducing x2, inducing points and hyper-parameters trained together"}
+
+
+def scattered_bench(eng, N=100000, m=32, kind="matern12", steps=10, warmup=3):
+    """Scattered observations (along-track points, vggp_elbo_step_scattered): ms per step for N points that form no grid,
+    B0 cells with m_d = 32 (M = 1024) -- O(M^2 N) assembly + O(M^3) dense factorisation."""
+    import torch
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (N, 2))
+    y = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.1 * rng.standard_normal(N)
+    g = np.linspace(0, 1, m + 1)
+    eng.plan(kind, "b0", g, X[:, 0].copy(), kind, "b0", g, X[:, 1].copy(), scattered=True)
+    yd = torch.tensor(y, device=eng.device)
+    yy = float(y @ y)
+    opt = Adam(raw_start(), lr=0.01)
+
+    def one():
+        raw = opt.x
+        e, gr, info = eng.elbo_step_scattered(yd, yy, theta_from_raw(raw.copy()))
+        opt.step(-(gr / (1.0 + np.exp(-raw))))
+        return e
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e = one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    M = m * m
+    return {"points": N, "m_d": m, "M": M, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "elbo_last": e,
+            "assembly_flops": 3 * 2.0 * M * M * N, "assembly_TFLOP/s_if_all_time": 3 * 2.0 * M * M * N / (ms * 1e-3) / 1e12}
 
 
 def factor_build_bench(eng, n=8192, reps=5):
