@@ -221,7 +221,8 @@ static void vgm_layout(VgMasked& w, char* base, size_t& off) {
     w.DI = take((size_t)w.nblk * VG_MB * VG_MB); w.Tmp = take((size_t)VG_MB * M);
     w.PP1 = take(m1 * m1 * n1); w.PP1v = take(m1 * m1 * n1); w.PP2 = take(m2 * m2 * n2); w.PP2v = take(m2 * m2 * n2);
     const size_t grid = w.scattered ? n1 : n1 * n2;            // scattered: zb, zv1, zv2 are per-point vectors
-    w.T = take(w.scattered ? 256 : n1 * m2 * m2); w.Tv = take(w.scattered ? 256 : n1 * m2 * m2);
+    w.T = take(w.scattered ? 256 * (m1 > m2 ? m1 * m1 : m2 * m2) : n1 * m2 * m2);      // scattered: split-K slabs of the small long-K products
+    w.Tv = take(w.scattered ? 256 : n1 * m2 * m2);
     w.UB = take(m1 * n2); w.UV = take(m1 * n2); w.Zb = take(grid); w.Zv1 = take(grid); w.Zv2 = take(grid);
     w.B1s = take(m1 * n1); w.B2s = take(m2 * n2);
     w.nb1 = take(n1); w.nb2 = take(n2); w.hv1 = take(n1); w.hv2 = take(n2); w.wn1 = take(n2);
@@ -269,6 +270,26 @@ static int gemm1(const double* A, long sa_m, long sa_k, const double* B, long sb
     vg_gemm_init(&g);
     vg_gemm_add(&g, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, M, N, K, 1, 0, 1, 0, alpha, accum);
     VG_HIP(vg_gemm_launch(&g, st));
+    return VGGP_OK;
+}
+
+// C (M x N, contiguous) = A B with a SHORT output and a LONG reduction (m x m results summed over 1e5 points): one workgroup per
+// tile would walk the whole K alone (5.8 ms at K = 100 000, measured), so the reduction is split over up to 256 workgroups whose
+// slabs are summed in fixed order.  scratch: >= 256 * M * N doubles.
+static int gemm_longk(const double* A, long sa_m, long sa_k, const double* B, long sb_k, long sb_n, double* C, int M, int N, int K,
+                      double* scratch, hipStream_t st) {
+    int ks = K / 512;
+    if (ks > 256) ks = 256;
+    if (ks < 2) return gemm1(A, sa_m, sa_k, B, sb_k, sb_n, C, N, M, N, K, st);
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    const int ip = vg_gemm_add(&g, A, sa_m, sa_k, B, sb_k, sb_n, scratch, N, M, N, K, ks, (long)M * N);
+    const int slabs = g.p[ip].ksplit;
+    VG_HIP(vg_gemm_launch(&g, st));
+    VgRedBatch r;
+    vg_red_init(&r);
+    vg_red_add(&r, scratch, C, (long)M * N, (long)M * N, slabs);
+    VG_HIP(vg_red_launch(&r, st));
     return VGGP_OK;
 }
 
@@ -486,9 +507,9 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
     // projections: C0 = B1 diag(y) B2^T, C1 = V1 diag(y) B2^T, C2 = B1 diag(y) V2^T   (m1 x m2, K = N)
     VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * N, st, B1, y, (int)m1, N, w.B1s);
     VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * N, st, V1, y, (int)m1, N, w.UV);           // (UV is free until the a0 stage)
-    if ((rc = gemm1(w.B1s, N, 1, B2, 1, N, C0, (int)m2, (int)m1, (int)m2, (int)N, st))) return rc;
-    if ((rc = gemm1(w.UV, N, 1, B2, 1, N, C1, (int)m2, (int)m1, (int)m2, (int)N, st))) return rc;
-    if ((rc = gemm1(w.B1s, N, 1, V2, 1, N, C2, (int)m2, (int)m1, (int)m2, (int)N, st))) return rc;
+    if ((rc = gemm_longk(w.B1s, N, 1, B2, 1, N, C0, (int)m1, (int)m2, (int)N, w.T, st))) return rc;
+    if ((rc = gemm_longk(w.UV, N, 1, B2, 1, N, C1, (int)m1, (int)m2, (int)N, w.T, st))) return rc;
+    if ((rc = gemm_longk(w.B1s, N, 1, V2, 1, N, C2, (int)m1, (int)m2, (int)N, w.T, st))) return rc;
     // per-point statistics
     VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B1, B1, (int)m1, N, w.nb1);
     VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B2, B2, (int)m2, N, w.nb2);
@@ -519,8 +540,8 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
     // PT_d = B_d diag(|b_other|^2) B_d^T, partial traces of Sinv
     VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * N, st, B1, w.nb2, (int)m1, N, w.B1s);
     VGM_LAUNCH1D(vgm_scalecols_kernel, m2 * N, st, B2, w.nb1, (int)m2, N, w.B2s);
-    if ((rc = gemm1(w.B1s, N, 1, B1, 1, N, w.PT1, (int)m1, (int)m1, (int)m1, (int)N, st))) return rc;
-    if ((rc = gemm1(w.B2s, N, 1, B2, 1, N, w.PT2, (int)m2, (int)m2, (int)m2, (int)N, st))) return rc;
+    if ((rc = gemm_longk(w.B1s, N, 1, B1, 1, N, w.PT1, (int)m1, (int)m1, (int)N, w.T, st))) return rc;
+    if ((rc = gemm_longk(w.B2s, N, 1, B2, 1, N, w.PT2, (int)m2, (int)m2, (int)N, w.T, st))) return rc;
     VGM_LAUNCH1D(vgm_ptrace_kernel, m1 * m1, st, w.Sinv, (int)m1, (int)m2, 1, w.PTS1);
     VGM_LAUNCH1D(vgm_ptrace_kernel, m2 * m2, st, w.Sinv, (int)m1, (int)m2, 2, w.PTS2);
     VgmRedArgs ra;
