@@ -410,8 +410,9 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     // PT_d = B_d diag(w) B_d^T, partial traces of Sinv
     VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * n1, st, B1, w.wn2, (int)m1, n1, w.B1s);
     VGM_LAUNCH1D(vgm_scalecols_kernel, m2 * n2, st, B2, w.wn1, (int)m2, n2, w.B2s);
-    if ((rc = gemm1(w.B1s, n1, 1, B1, 1, n1, w.PT1, (int)m1, (int)m1, (int)m1, (int)n1, st))) return rc;
-    if ((rc = gemm1(w.B2s, n2, 1, B2, 1, n2, w.PT2, (int)m2, (int)m2, (int)m2, (int)n2, st))) return rc;
+    // (short outputs, long reductions: split-K with the assembly's T buffer -- free by now -- as slab scratch)
+    if ((rc = gemm_longk(w.B1s, n1, 1, B1, 1, n1, w.PT1, (int)m1, (int)m1, (int)n1, w.T, st))) return rc;
+    if ((rc = gemm_longk(w.B2s, n2, 1, B2, 1, n2, w.PT2, (int)m2, (int)m2, (int)n2, w.T, st))) return rc;
     VGM_LAUNCH1D(vgm_ptrace_kernel, m1 * m1, st, w.Sinv, (int)m1, (int)m2, 1, w.PTS1);
     VGM_LAUNCH1D(vgm_ptrace_kernel, m2 * m2, st, w.Sinv, (int)m1, (int)m2, 2, w.PTS2);
     // reductions
