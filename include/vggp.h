@@ -184,6 +184,11 @@ int vggp_posterior_masked(vggp_ctx* ctx, const double* xs1, const double* xs2, i
 int vggp_readout(vggp_ctx* ctx, const double* C1, int64_t mv1, const double* C2, int64_t mv2, const double* kd1, const double* kd2,
                  double* mean, double* var, int flags, void* stream);
 
+/* The same read-out from the M-space state of the last MASKED or SCATTERED step (the Gridded* models on data that is no full
+ * grid: along-track observations, notebook 61); arguments as vggp_readout. */
+int vggp_readout_masked(vggp_ctx* ctx, const double* C1, int64_t mv1, const double* C2, int64_t mv2, const double* kd1, const double* kd2,
+                        double* mean, double* var, int flags, void* stream);
+
 /* q(v) of the last finished step: mean and diagonal of the covariance, both DEVICE
  * [m1][m2] (flat index u = i1*m2+i2).  Replaces Matern12GriddedGP.q_v
  * (gridded_kronecker_structure.py:1409-1433 == kronecker_structure.py:825-849). */

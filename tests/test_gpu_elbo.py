@@ -614,3 +614,33 @@ def test_scattered_step_vs_oracle(engine, basis, kind, g1, g2, N):
     assert rel(pm.cpu().numpy(), qm) < 1e-6 and rel(pv.cpu().numpy(), qv) < 1e-6
     with pytest.raises(Exception):
         engine.elbo_step(torch.zeros(N, N, dtype=torch.float64, device=DEV)[:2], 0.0, th)      # grid step on a scattered plan
+
+
+@pytest.mark.parametrize("literal", [True, False], ids=["literal", "conditional"])
+def test_readout_masked_equals_full_grid_readout(engine, literal):
+    """vggp_readout_masked (gridded read-out from the dense M-space state of a masked / scattered step) on a fully observed grid
+    -- as a masked step with W = 1 and as a scattered step over the grid's points -- must reproduce vggp_readout of the
+    Kronecker path, which is pinned on the oracle (test_gridded_readout_vs_oracle)."""
+    n1, n2, m1, m2, mv = 40, 36, 9, 8, 12
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    g1, g2 = np.linspace(0, 1, m1), np.linspace(0, 1, m2)
+    th = np.array([0.25, 0.3, 1.1, 0.9, 0.02])
+    mesh = np.linspace(0, 1, mv + 1)
+    f1, f2 = Kr.Factor("points", "matern12", g1, x1), Kr.Factor("points", "matern12", g2, x2)
+    C1, kdv1 = Kr.cross_b0(f1, mesh, th[0])
+    C2, kdv2 = Kr.cross_b0(f2, mesh, th[1])
+    kd1, kd2 = torch.tensor(kdv1), torch.tensor(kdv2)
+    C1t, C2t = torch.tensor(C1), torch.tensor(C2)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    engine.plan("matern12", "points", g1, x1, "matern12", "points", g2, x2)
+    engine.elbo_step(Y, engine.sumsq(Y), th)
+    mean0, var0 = engine.readout(C1t, C2t, kd1, kd2, literal=literal)
+    W = torch.ones_like(Y)
+    engine.elbo_step_masked(Y, W, float(n1 * n2), engine.sumsq(Y), th)
+    mean1, var1 = engine.readout(C1t, C2t, kd1, kd2, literal=literal, masked=True)
+    assert rel(mean1.cpu().numpy(), mean0.cpu().numpy()) < 1e-8 and rel(var1.cpu().numpy(), var0.cpu().numpy()) < 1e-8
+    engine.plan("matern12", "points", g1, X[:, 0].copy(), "matern12", "points", g2, X[:, 1].copy(), scattered=True)
+    yd = torch.tensor(y, device=DEV)
+    engine.elbo_step_scattered(yd, float(y @ y), th)
+    mean2, var2 = engine.readout(C1t, C2t, kd1, kd2, literal=literal, masked=True)
+    assert rel(mean2.cpu().numpy(), mean0.cpu().numpy()) < 1e-8 and rel(var2.cpu().numpy(), var0.cpu().numpy()) < 1e-8

@@ -254,6 +254,36 @@ def test_gridded_vff_model_vs_dense(engine):
     assert rel(qu.mean.numpy(), qud.mean.detach().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("data", ["masked", "scattered"])
+def test_gridded_vff_model_readout_on_incomplete_data_vs_dense(engine, data):
+    """GriddedMatern12VFFGP.q_v() when the observations are a grid with holes or scattered points (vggp_readout_masked: the
+    read-out from the dense M-space state) against the literal dense formulas on the same points."""
+    import variational_gridded_gaussian_processes_amd.models as M
+    n1, n2, nf, ns = 24, 20, 5, 7
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    rng = np.random.default_rng(5)
+    keep = rng.random(len(y)) > 0.3
+    X, y = X[keep], y[keep]
+    if data == "scattered":
+        X = np.clip(X + rng.normal(scale=4e-3, size=X.shape), 0.0, 1.0)
+    lims = (-0.1, 1.1)
+    model = M.GriddedMatern12VFFGP(torch.tensor(X), torch.tensor(y), nf, lims, lims, ns, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    assert model._masked and model._scattered == (data == "scattered")
+    dm = D.DenseKron(X, y, "vff", "matern12", (lims[0], lims[1], nf), (lims[0], lims[1], nf))
+    mesh = torch.linspace(0, 1, ns + 1)
+    for literal in (True, False):
+        qd = dm.q_v_gridded(mesh, mesh, literal=literal)
+        qv = model.q_v(literal=literal)
+        assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5
+        assert rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+    # the SVGP-in-points gridded class (gridded_kronecker_structure.py:222-460) on the same points
+    z = torch.linspace(0, 1, 6, dtype=torch.float64)
+    sv = M.GriddedMatern12SVGP(torch.tensor(X), torch.tensor(y), torch.cartesian_prod(z, z), ns, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    ds = D.DenseKron(X, y, "points", "matern12", z, z)
+    qd, qv = ds.q_v_gridded(mesh, mesh), sv.q_v()
+    assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5 and rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("cls", ["b0", "vff", "points"])
 def test_posterior_dense_covariance_vs_dense_restatement(engine, cls):
     """posterior(x*).covariance_matrix -- the reference's dense N* x N* matrix (kronecker_structure.py:223-229) -- and

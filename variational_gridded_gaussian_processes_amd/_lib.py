@@ -66,6 +66,7 @@ SYMBOLS = {
     "vggp_set_inducing": (_I, [_P, C.c_int, _P, C.c_int64]),
     "vggp_posterior": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "vggp_readout": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P, _P, _I, _P]),
+    "vggp_readout_masked": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P, _P, _I, _P]),
     "vggp_posterior_masked": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "vggp_posterior_cov": (_I, [_P, _P, _P, _I64, _P, _P]),
     "vggp_posterior_cov_masked": (_I, [_P, _P, _P, _I64, _P, _P]),

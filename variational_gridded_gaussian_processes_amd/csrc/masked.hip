@@ -637,6 +637,75 @@ __global__ void vgm_post_kernel(const double* T, const double* ST, const double*
     var[p] = ss * (1.0 - nrm + quad);
 }
 
+// gridded read-out: cell p = a * mv2 + b; column p of T1x / T2x is column a of U1 / column b of U2
+__global__ void vgm_expand_kernel(const double* U1, const double* U2, int m1, int m2, long mv1, long mv2, long p0, long cn,
+                                  double* T1x, double* T2x) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)(m1 + m2) * cn) return;
+    const long row = idx / cn, q = idx - row * cn, p = p0 + q;
+    const long a = p / mv2, b = p - a * mv2;
+    if (row < m1) T1x[row * cn + q] = U1[row * mv1 + a];
+    else T2x[(row - m1) * cn + q] = U2[(row - m1) * mv2 + b];
+}
+// mean = (s1 s2 / v) t^T a0;  var = s1 s2 (kd1_a kd2_b - |t|^2 + quad), quad = t^T Sinv t (conditional) or |Lc^T t|^2 (literal:
+// t^T Sigma~ t, i.e. X = S_u^-1 in the reference's expression)
+__global__ void vgm_readout_kernel(const double* T, const double* ST, const double* a0, long M, long cn, const double* theta,
+                                   const double* kd1, const double* kd2, long mv2, long p0, int literal, double* mean, double* var) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= cn) return;
+    double lin = 0.0, nrm = 0.0, quad = 0.0;
+    for (long u = 0; u < M; ++u) {
+        const double t = T[u * cn + q], s = ST[u * cn + q];
+        lin += t * a0[u];
+        nrm += t * t;
+        quad += literal ? s * s : t * s;
+    }
+    const long p = p0 + q, a = p / mv2, b = p - a * mv2;
+    const double ss = theta[2] * theta[3];
+    mean[p] = (ss / theta[4]) * lin;
+    var[p] = ss * (kd1[a] * kd2[b] - nrm + quad);
+}
+
+// Gridded read-out q(v) of B0 cell features from the M-space state of the last masked / scattered step (the Gridded* models of
+// gridded_kronecker_structure.py:396-438 / :613-654 / :903-947 on data that is no full grid -- the along-track case of notebook
+// 61): arguments and meaning as vggp_readout.  t = (L0_1^-1 C1^T)[:, a] (x) (L0_2^-1 C2^T)[:, b]: the point-wise posterior's algebra
+// with the cross-covariances in place of the kernel columns and kd1_a kd2_b in place of the unit prior variance.
+extern "C" int vggp_readout_masked(vggp_ctx* c, const double* C1, int64_t mv1, const double* C2, int64_t mv2, const double* kd1,
+                                   const double* kd2, double* mean, double* var, int flags, void* stream) {
+    if (!c || !c->have_masked || !c->masked) { vg_set_error("vggp_readout_masked: no finished masked / scattered step"); return VGGP_ESTATE; }
+    VG_REQUIRE(C1 && C2 && kd1 && kd2 && mean && var && mv1 > 0 && mv2 > 0, "vggp_readout_masked: bad argument");
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
+    const long m1 = w.m1, m2 = w.m2, M = w.M, ns = mv1 * mv2;
+    const int literal = (flags & VGGP_READOUT_LITERAL) ? 1 : 0;
+    const long chunk = std::min<long>(ns, M);            // T and (Sinv | Lc^T) T live in the two M x M scratch matrices
+    int rc = vg_ensure_misc(c, (size_t)(m1 * mv1 + m2 * mv2 + chunk * (m1 + m2)) * sizeof(double));
+    if (rc) return rc;
+    double* p = (double*)c->misc;
+    double* U1 = p; p += m1 * mv1;
+    double* U2 = p; p += m2 * mv2;
+    double* T1x = p; p += m1 * chunk;
+    double* T2x = p;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    VgGemmBatch g;
+    vg_gemm_init(&g);                                    // U_d = Linv0_d C_d^T   (m_d x mv_d)
+    vg_gemm_add(&g, d1.Linv0, m1, 1, C1, 1, m1, U1, (int)mv1, (int)m1, (int)mv1, (int)m1);
+    vg_gemm_add(&g, d2.Linv0, m2, 1, C2, 1, m2, U2, (int)mv2, (int)m2, (int)mv2, (int)m2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    for (long off = 0; off < ns; off += chunk) {
+        const long cn = std::min<long>(chunk, ns - off);
+        VGM_LAUNCH1D(vgm_expand_kernel, (m1 + m2) * cn, st, U1, U2, (int)m1, (int)m2, (long)mv1, (long)mv2, off, cn, T1x, T2x);
+        VGM_LAUNCH1D(vgm_pairprod_kernel, M * cn, st, T1x, T2x, (int)m1, (int)m2, cn, w.R);
+        if (literal) { if ((rc = gemm1(w.Lg, 1, M, w.R, cn, 1, w.Sg, (int)cn, (int)M, (int)cn, (int)M, st))) return rc; }     // Lc^T T
+        else if ((rc = gemm1(w.Sinv, M, 1, w.R, cn, 1, w.Sg, (int)cn, (int)M, (int)cn, (int)M, st))) return rc;
+        VGM_LAUNCH1D(vgm_readout_kernel, cn, st, w.R, w.Sg, w.a0, M, cn, c->theta, kd1, kd2, (long)mv2, off, literal, mean, var);
+    }
+    VG_HIP(hipGetLastError());
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}
+
 // posterior(x*) of the last masked step (kronecker_structure.py:199-230 on the observed subset):
 //   t = (L1^{-1} a1(x*)) (x) (L2^{-1} a2(x*)),  mean = rho t^T a0,  var = s1 s2 (1 - |t|^2 + t^T Sigma~^{-1} t)
 extern "C" int vggp_posterior_masked(vggp_ctx* c, const double* xs1, const double* xs2, int64_t ns, double* mean, double* var,

@@ -226,7 +226,8 @@ class Engine:
         check(self.lib.vggp_qv_cov(self._h, _ptr(cov), _stream(self.device)))
         return cov
 
-    def readout(self, C1: torch.Tensor, C2: torch.Tensor, kd1: torch.Tensor, kd2: torch.Tensor, literal: bool = True):
+    def readout(self, C1: torch.Tensor, C2: torch.Tensor, kd1: torch.Tensor, kd2: torch.Tensor, literal: bool = True,
+                masked: bool = False):
         """Gridded read-out q(v) of B0 cell features from the inducing posterior of the last step (include/vggp.h):
         C_d [mv_d, m_d] unit-outputscale cross-covariances, kd_d [mv_d] unit diagonals of Kvv_d -> mean, var [mv1, mv2]."""
         C1, C2 = C1.to(self.device, torch.float64).contiguous(), C2.to(self.device, torch.float64).contiguous()
@@ -235,8 +236,9 @@ class Engine:
             raise ValueError("C_d must be [mv_d, m_d]")
         mean = torch.empty(C1.shape[0], C2.shape[0], dtype=torch.float64, device=self.device)
         var = torch.empty_like(mean)
-        check(self.lib.vggp_readout(self._h, _ptr(C1), C1.shape[0], _ptr(C2), C2.shape[0], _ptr(kd1), _ptr(kd2), _ptr(mean),
-                                    _ptr(var), 1 if literal else 0, _stream(self.device)))
+        fn = self.lib.vggp_readout_masked if masked else self.lib.vggp_readout      # masked: state of a masked / scattered step
+        check(fn(self._h, _ptr(C1), C1.shape[0], _ptr(C2), C2.shape[0], _ptr(kd1), _ptr(kd2), _ptr(mean),
+                 _ptr(var), 1 if literal else 0, _stream(self.device)))
         return mean, var
 
     def posterior_cov(self, x_star: torch.Tensor, masked: bool = False) -> torch.Tensor:

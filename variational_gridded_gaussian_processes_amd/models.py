@@ -506,7 +506,7 @@ class GriddedMatern12VFFGP(Matern12VFFGP):
         l2 = self.kernel_2.base_kernel.lengthscale.reshape(()).item()
         kd1 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.delta_1.double()), l1), dtype=torch.float64)
         kd2 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.delta_2.double()), l2), dtype=torch.float64)
-        mean, var = self._engine.readout(C1, C2, kd1, kd2, literal=literal)
+        mean, var = self._engine.readout(C1, C2, kd1, kd2, literal=literal, masked=self._masked)
         return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
 
 
@@ -549,7 +549,7 @@ class _GriddedReadout:
         l2 = self.kernel_2.base_kernel.lengthscale.reshape(()).item()
         kd1 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.b0_delta_1.double()), l1), dtype=torch.float64)
         kd2 = torch.full((self.nsplines,), _b0_kvv_diag_unit(float(self.b0_delta_2.double()), l2), dtype=torch.float64)
-        mean, var = self._engine.readout(self._cross(0, l1), self._cross(1, l2), kd1, kd2, literal=literal)
+        mean, var = self._engine.readout(self._cross(0, l1), self._cross(1, l2), kd1, kd2, literal=literal, masked=self._masked)
         return MultivariateNormal(mean.reshape(-1).cpu(), var.reshape(-1).cpu())
 
 
