@@ -226,9 +226,10 @@ static void vgm_layout(VgMasked& w, char* base, size_t& off) {
     w.UB = take(m1 * n2); w.UV = take(m1 * n2); w.Zb = take(grid); w.Zv1 = take(grid); w.Zv2 = take(grid);
     w.B1s = take(m1 * n1); w.B2s = take(m2 * n2);
     w.nb1 = take(n1); w.nb2 = take(n2); w.hv1 = take(n1); w.hv2 = take(n2); w.wn1 = take(n2);
-    w.mpay = take(2 * m2 * m2 + 3 * M + n1 + 3 * MM);
+    const size_t wn2len = w.scattered ? 0 : n1;                 // (scattered: the all-reduce payload is C, C1, C2 | R3, the same
+    w.mpay = take(2 * m2 * m2 + 3 * M + wn2len + 3 * MM);       //  length on every rank whatever its number of points)
     w.wn2 = base ? w.mpay + 2 * m2 * m2 + 3 * M : nullptr;
-    w.R3 = base ? w.wn2 + n1 : nullptr;
+    w.R3 = base ? w.wn2 + wn2len : nullptr;
     w.scal = take(32);
     w.PT1 = take(m1 * m1); w.PT2 = take(m2 * m2); w.PTS1 = take(m1 * m1); w.PTS2 = take(m2 * m2);
     w.MkA1 = take(M); w.MkA2 = take(M); w.a0 = take(M);
@@ -481,13 +482,13 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
 // GEMM over the points between the row-pair products, R[(i1,k1),(i2,k2)] = sum_k (B1[i1,k] B1[k1,k]) (B2[i2,k] B2[k2,k]);
 // everything after the assembly -- dense factorisation of Sigma~ = I + rho Phi~0, a0, the gradient's scalars, the final
 // combination, the read-outs -- is the masked step's, with sums over observed grid points replaced by sums over the points.
-// Specification: oracle/kron.py elbo_step_scattered (== the literal dense restatement to 1e-14).  Single rank.
+// Specification: oracle/kron.py elbo_step_scattered (== the literal dense restatement to 1e-14).  Several ranks: each plans ITS
+// points (desc.n_total = the number of points over all ranks, yy = the global sum of squares) -- two all-reduces, see below.
 extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy, const double theta[5], double* elbo_out,
                                         double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step_scattered: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(y && theta && elbo_out && grad_out, "vggp_elbo_step_scattered: null argument");
     VG_REQUIRE(c->desc.flags & VGGP_FLAG_SCATTERED, "vggp_elbo_step_scattered: plan the context with VGGP_FLAG_SCATTERED");
-    VG_REQUIRE(!(c->n_ranks > 1 || c->comm || c->cb), "vggp_elbo_step_scattered: row-sharded contexts are not supported");
     c->have_masked = false;
     const long m1 = c->desc.m1, m2 = c->desc.m2, N = c->desc.n1, M = m1 * m2;
     VG_REQUIRE(M <= 8192, "vggp_elbo_step_scattered: M = m1*m2 = %ld too large for the dense solver (<= 8192)", M);
@@ -525,6 +526,9 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
     if ((rc = gemm1(w.PP1, N, 1, w.PP2, 1, N, w.R3, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)N, st))) return rc;
     if ((rc = gemm1(w.PP1v, N, 1, w.PP2, 1, N, w.R3 + M * M, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)N, st))) return rc;
     if ((rc = gemm1(w.PP1, N, 1, w.PP2v, 1, N, w.R3 + 2 * M * M, (int)(m2 * m2), (int)(m1 * m1), (int)(m2 * m2), (int)N, st))) return rc;
+    // point-sharded job (n_ranks > 1: every rank holds its own points): C0, C1, C2 and the three assembly matrices are partial
+    // sums over this rank's points -- ONE all-reduce of 3 M + 3 M^2 doubles, then Sigma~, its factorisation and a0 are replicated
+    if ((rc = vg_allreduce(c, C0, 3 * M + 3 * M * M, st))) return rc;
     VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3, (int)m1, (int)m2, c->theta, 1, w.Sg);
     VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3 + M * M, (int)m1, (int)m2, c->theta, 0, w.Phip);
     VGM_LAUNCH1D(vgm_permute_kernel, M * M, st, w.R3 + 2 * M * M, (int)m1, (int)m2, c->theta, 0, w.Phip + M * M);
@@ -573,8 +577,13 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
     job(RJ_HV2, w.hv2, w.nb1, N, 1, 1, 0);
     job(RJ_MK2PT, d2.Mk, w.PT2, m2 * m2, 1, 1, 0);
     hipLaunchKernelGGL(vgm_red_kernel, dim3(VG_MD_NPART, RJ_COUNT), dim3(256), 0, st, ra);
-    hipLaunchKernelGGL(vgm_sum_kernel, dim3(1), dim3(64), 0, st, w.partial, w.scal, 0u, 1);
-    VgmFinalArgs fa{c->theta, w.scal, w.out, (double)N, yy, (int)m1, (int)m2};
+    // scalars that are sums over this rank's points (everything else is replicated): second, tiny collective
+    const unsigned local_mask = (1u << RJ_TRPHI) | (1u << RJ_Z1) | (1u << RJ_HV1) | (1u << RJ_MK1PT) | (1u << RJ_Z2) | (1u << RJ_HV2) |
+                                (1u << RJ_MK2PT);
+    const bool multi = c->n_ranks > 1 || c->comm || c->cb;
+    hipLaunchKernelGGL(vgm_sum_kernel, dim3(1), dim3(64), 0, st, w.partial, w.scal, local_mask, (!multi || c->rank == 0) ? 1 : 0);
+    if ((rc = vg_allreduce(c, w.scal, RJ_COUNT, st))) return rc;
+    VgmFinalArgs fa{c->theta, w.scal, w.out, (double)(c->desc.n_total > N ? c->desc.n_total : N), yy, (int)m1, (int)m2};
     hipLaunchKernelGGL(vgm_final_kernel, dim3(1), dim3(64), 0, st, fa);
     VG_HIP(hipGetLastError());
     VG_HIP(hipMemcpyAsync(c->h_out->out, w.out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -132,7 +132,7 @@ class Engine:
         if scattered:          # x1[k], x2[k]: the coordinates of point k (no grid)
             if len(x1) != len(x2):
                 raise ValueError("scattered plan: x1 and x2 must hold one coordinate pair per point")
-            d.n_total = len(x1)
+            d.n_total = int(n_total) if n_total is not None else len(x1)      # (point-sharded job: points over all ranks)
         self.scattered = bool(scattered)
         with torch.cuda.device(self.device):
             check(self.lib.vggp_plan(self._h, C.byref(d)))
