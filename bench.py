@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
   svgp_train_z      ms per optimiser iteration of an SVGP whose inducing points are trained (step + Z-gradient + in-place move)
   scattered         vggp_elbo_step_scattered: ms per step for 100 000 points that form no grid (B0 cells, m_d = 32)
+  masked_md128      masked 2048 x 2048 grid, 30 % missing, m_d = 128 (M = 16384): ms per step of the dense M-space solver
   slab_1024x4096    the per-rank shape of BASELINE configs[3]: ms per step, and the projection kernel's MFMA fraction at that size
   kron_solve        BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
   factor_build      HBM-write rate of the factor kernel at m = n = 8192
@@ -359,6 +360,7 @@ def main():
             out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
             out["svgp_train_z"] = trainz_bench(eng, Y, yy, x1, x2, m)
             out["scattered"] = scattered_bench(eng)
+            out["masked_md128"] = masked_md128_bench(eng, D)
             out["kron_solve"] = kron_solve_bench(eng, 1024)
             out["factor_build"] = factor_build_bench(eng)
         if not args.no_cpu and world == 1 and not args.masked:
@@ -448,6 +450,27 @@ def trainz_bench(eng, Y, yy, x1, x2, m, kind="matern32", steps=60, warmup=15):
     torch.cuda.synchronize()
     return {"kind": kind, "ms_per_iteration": (time.perf_counter() - t0) / steps * 1e3, "elbo_last": e,
             "what": "elbo_step + zgrad + set_inducing x2, inducing points and hyper-parameters trained together"}
+
+
+def masked_md128_bench(eng, D, n=2048, m=128, kind="matern12", steps=3):
+    """BASELINE configs[4] grid (2048 x 2048, 30 % missing) at the headline's inducing count: m_d = 128, M = 16384 -- the dense
+    M-space solver at the top of its range (21 GB of workspace, O(M^3) per step)."""
+    import torch
+    X, y, x1, x2 = D.gen_grid(n, n)
+    del X
+    mesh = np.linspace(0, 1, m + 1)
+    W = torch.tensor((np.random.default_rng(1).uniform(size=(n, n)) < 0.7).astype(np.float64), device=eng.device)
+    Ym = torch.tensor(y.reshape(n, n), device=eng.device) * W
+    eng.plan(kind, "b0", mesh, x1, kind, "b0", mesh, x2)
+    yy, nobs = eng.sumsq(Ym), float(W.sum().item())
+    eng.elbo_step_masked(Ym, W, nobs, yy, THETA0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        e, gr, info = eng.elbo_step_masked(Ym, W, nobs, yy, [t * (1 + 0.01 * (k + 1)) for t in THETA0])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"n": n, "m_d": m, "M": m * m, "ms_per_step": dt * 1e3, "observed_points_per_s": nobs / dt, "elbo_last": e}
 
 
 def scattered_bench(eng, N=100000, m=32, kind="matern12", steps=10, warmup=3):

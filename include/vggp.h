@@ -159,7 +159,7 @@ int vggp_elbo_finish(vggp_ctx* ctx, const double* payload, double yy_total, cons
                      double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 
 /* Masked / partially observed grid (BASELINE config 5).  Ym = W o Y and W (0/1 as float64) are DEVICE [n2][n1] (this rank's
- * row slab); n_obs = sum(W), yy_obs = sum(Ym^2) over ALL ranks.  Phi = Kuf W Kuf^T is assembled in M-space (M = m1 m2 <= 8192)
+ * row slab); n_obs = sum(W), yy_obs = sum(Ym^2) over ALL ranks.  Phi = Kuf W Kuf^T is assembled in M-space (M = m1 m2 <= 16384)
  * and factored densely; value + analytic gradient as for vggp_elbo_step.  Replaces KroneckerStructure._elbo
  * (kronecker_structure.py:249-278) called with the observed subset of the grid as X, y.
  * Multi-rank context: every rank assembles the partial Phi_r (and its two lengthscale derivatives, the projections and a
@@ -209,7 +209,7 @@ int vggp_zgrad(vggp_ctx* ctx, const double* Y, double* gz1, double* gz2, void* s
  * :249-278, receives arbitrary (x1, x2) pairs in notebooks 6 / 61 / 7 and evaluates Kuf densely, :808-823).  The context must have
  * been planned with VGGP_FLAG_SCATTERED (x1[k], x2[k] = the coordinates of point k, n1 = n2 = N).  y [N] device, yy = sum y^2.
  * Kuf[:, k] = a1(x1_k) (x) a2(x2_k) is a Khatri-Rao product: Sigma~ = I + rho sum_k (b1_k (x) b2_k)(b1_k (x) b2_k)^T is assembled
- * in M-space (M = m1 m2 <= 8192) by one GEMM over the points and factored densely, as in the masked step; cost O(M^2 N + M^3).
+ * in M-space (M = m1 m2 <= 16384) by one GEMM over the points and factored densely, as in the masked step; cost O(M^2 N + M^3).
  * vggp_qv_masked / vggp_posterior_masked / the *_cov_masked entries read the result. */
 int vggp_elbo_step_scattered(vggp_ctx* ctx, const double* y, double yy, const double theta[5], double* elbo_out,
                              double grad_out[5], vggp_info* info, void* stream);

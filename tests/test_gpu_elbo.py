@@ -265,6 +265,39 @@ def test_config5_full_size_masked_2048_vs_structured_oracle(engine):
     assert abs(e_m - e_k) <= 1e-8 * abs(e_k) and rel(g_m, g_k) < 1e-6
 
 
+def test_masked_step_at_md128_and_md96(engine):
+    """The dense M-space solver above M = 8192 (blocked Cholesky / inverse with the triangular skips, 64-bit offsets): m_d = 128
+    (M = 16384, config 5's grid at the headline's inducing count) with everything observed equals the Kronecker path, which is
+    pinned on the oracle; and at m_d = 96 (M = 9216) a grid with 30 % holes equals the scattered step on the observed points --
+    two independent assemblies (mask-weighted grid products / Khatri-Rao over points) into the same solver.  No CPU oracle at
+    these sizes (a dense 16384^3 factorisation in numpy takes minutes)."""
+    th = [0.2, 0.3, 1.0, 0.8, 0.01]
+    n, m = 256, 128
+    X, y, x1, x2 = D.gen_grid(n, n)
+    mesh = np.linspace(0, 1, m + 1)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    engine.plan("matern12", "b0", mesh, x1, "matern12", "b0", mesh, x2)
+    e_k, g_k, _ = engine.elbo_step(Y, engine.sumsq(Y), th)
+    mean_k, var_k = engine.qv()
+    e_m, g_m, _ = engine.elbo_step_masked(Y, torch.ones_like(Y), float(n * n), engine.sumsq(Y), th)
+    assert abs(e_m - e_k) <= 1e-7 * abs(e_k) and rel(g_m, g_k) < 1e-6
+    mean_m, var_m = engine.qv_masked()
+    assert rel(mean_m.cpu().numpy(), mean_k.cpu().numpy()) < 1e-6 and rel(var_m.cpu().numpy(), var_k.cpu().numpy()) < 1e-6
+    n, m = 192, 96
+    X, y, x1, x2 = D.gen_grid(n, n)
+    g = np.linspace(0, 1, m)
+    Wn = np.random.default_rng(2).uniform(size=(n, n)) < 0.7
+    W = torch.tensor(Wn.astype(np.float64), device=DEV)
+    Ym = torch.tensor(y.reshape(n, n), device=DEV) * W
+    engine.plan("matern32", "points", g, x1, "matern32", "points", g, x2)
+    e_m, g_m, _ = engine.elbo_step_masked(Ym, W, float(Wn.sum()), engine.sumsq(Ym), th)
+    obs = Wn.reshape(-1)
+    engine.plan("matern32", "points", g, X[obs, 0].copy(), "matern32", "points", g, X[obs, 1].copy(), scattered=True)
+    yo = y[obs]
+    e_s, g_s, _ = engine.elbo_step_scattered(torch.tensor(yo, device=DEV), float(yo @ yo), th)
+    assert abs(e_m - e_s) <= 1e-8 * abs(e_s) and rel(g_m, g_s) < 1e-6
+
+
 @pytest.mark.parametrize("kind,n", [("matern32", 512), ("rbf", 384), ("matern12", 300)])
 def test_md256_elbo_step_vs_structured_oracle(engine, kind, n):
     """m_d = 256 (the top of the m_d sweep of SURVEY.md section 8d and of vggp_plan's range): the factors no longer fit one

@@ -78,6 +78,7 @@ struct VgGemmP {
 #define VG_TRI_A_UPPER 2   // op(A)[i][k] = 0 for k < i:  k >= rounddown128(row0)
 #define VG_TRI_B_UPPER 3   // op(B)[k][j] = 0 for k > j:  k < roundup128(col0 + T)
 #define VG_TRI_B_LOWER 4   // op(B)[k][j] = 0 for k < j:  k >= rounddown128(col0)
+#define VG_TRI_A_UPPER_B_LOWER 5   // both (X^T X of a lower-triangular X):  k >= rounddown128(max(row0, col0))
 struct VgGemmBatch {
     int nprob;
     int total_tiles;

@@ -153,7 +153,8 @@ __device__ __forceinline__ void vg_gemm_deep_body(const VgGemmP& p, double* lds,
         if (p.tri == VG_TRI_A_LOWER) k_end = min(k_end, ((row0 + T + 127) >> 7) << 7);
         else if (p.tri == VG_TRI_A_UPPER) k_begin = max(k_begin, (row0 >> 7) << 7);
         else if (p.tri == VG_TRI_B_UPPER) k_end = min(k_end, ((col0 + T + 127) >> 7) << 7);
-        else k_begin = max(k_begin, (col0 >> 7) << 7);
+        else if (p.tri == VG_TRI_B_LOWER) k_begin = max(k_begin, (col0 >> 7) << 7);
+        else k_begin = max(k_begin, (max(row0, col0) >> 7) << 7);
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;      // 2 x 4 waves, each 32 rows x 16 columns

@@ -60,7 +60,8 @@ __device__ __forceinline__ void vg_gemm_body(const VgGemmBatch& b, double* lds, 
         if (p.tri == VG_TRI_A_LOWER) k_end = min(k_end, ((row0 + T + 127) >> 7) << 7);
         else if (p.tri == VG_TRI_A_UPPER) k_begin = max(k_begin, (row0 >> 7) << 7);
         else if (p.tri == VG_TRI_B_UPPER) k_end = min(k_end, ((col0 + T + 127) >> 7) << 7);
-        else k_begin = max(k_begin, (col0 >> 7) << 7);
+        else if (p.tri == VG_TRI_B_LOWER) k_begin = max(k_begin, (col0 >> 7) << 7);
+        else k_begin = max(k_begin, (max(row0, col0) >> 7) << 7);
     }
 
     const int tid = threadIdx.x;

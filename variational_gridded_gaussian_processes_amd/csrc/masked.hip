@@ -188,6 +188,7 @@ __global__ void vgm_scale_rho_kernel(double* x, long n, const double* theta, int
     if (i < n) x[i] *= (e1 > 0 ? theta[2] : 1.0) * (e2 > 0 ? theta[3] : 1.0) / theta[4];      // s_d^((1 + e_d) / 2) / sigma^2
 }
 
+#define VGM_MAX_M 16384      // dense M x M solver: ~10 M^2 doubles of workspace (21 GB at the limit), O(M^3) per step
 #define VGM_LAUNCH1D(kern, n, st, ...) \
     hipLaunchKernelGGL(kern, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, st, __VA_ARGS__)
 
@@ -316,8 +317,17 @@ int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st) {
             // panel: L[i, kb] = A[i, kb] Linv_kk^T ;  trailing: A[i, j] -= L[i, kb] L[j, kb]^T
             const double* DIk = w.DI + (long)kb * VG_MB * VG_MB;
             if ((rc = gemm1(w.S + (long)(k0 + nbk) * M + k0, M, 1, DIk, 1, nbk, w.L + (long)(k0 + nbk) * M + k0, M, rest, nbk, nbk, st))) return rc;
+            // (only the lower triangle of the trailing matrix is read later: column strips that start on the diagonal, one launch)
             const double* Lp = w.L + (long)(k0 + nbk) * M + k0;
-            if ((rc = gemm1(Lp, M, 1, Lp, 1, M, w.S + (long)(k0 + nbk) * M + (k0 + nbk), M, rest, rest, nbk, st, -1.0, 1))) return rc;
+            double* St = w.S + (long)(k0 + nbk) * M + (k0 + nbk);
+            const int nstrip = std::min(VG_GEMM_MAXP, (rest + 1023) / 1024);
+            const int wd = (((rest + nstrip - 1) / nstrip) + VG_MB - 1) / VG_MB * VG_MB;
+            VgGemmBatch g;
+            vg_gemm_init(&g);
+            for (int c0 = 0; c0 < rest; c0 += wd)
+                vg_gemm_add(&g, Lp + (long)c0 * M, M, 1, Lp + (long)c0 * M, 1, M, St + (long)c0 * M + c0, M, rest - c0, std::min(wd, rest - c0),
+                            nbk, 1, 0, 1, 0, -1.0, 1);
+            VG_HIP(vg_gemm_launch(&g, st));
         }
     }
     // blocked inverse of the lower factor: X[k,k] = inv(L_kk); X[i, :i] = -inv(L_ii) (L[i, :i] X[:i, :i])
@@ -326,11 +336,22 @@ int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st) {
         VG_HIP(hipMemcpy2DAsync(w.X + (long)k0 * M + k0, sizeof(double) * M, w.DI + (long)kb * VG_MB * VG_MB, sizeof(double) * nbk,
                                 sizeof(double) * nbk, nbk, hipMemcpyDeviceToDevice, st));
         if (kb == 0) continue;
-        if ((rc = gemm1(w.L + (long)k0 * M, M, 1, w.X, M, 1, w.Tmp, k0, nbk, k0, k0, st))) return rc;
+        {   // (X[:k0, :k0] is lower triangular: the tiles skip the k-range above their columns)
+            VgGemmBatch g;
+            vg_gemm_init(&g);
+            const int i = vg_gemm_add(&g, w.L + (long)k0 * M, M, 1, w.X, M, 1, w.Tmp, k0, nbk, k0, k0);
+            g.p[i].tri = VG_TRI_B_LOWER;
+            VG_HIP(vg_gemm_launch(&g, st));
+        }
         if ((rc = gemm1(w.DI + (long)kb * VG_MB * VG_MB, nbk, 1, w.Tmp, k0, 1, w.X + (long)k0 * M, M, nbk, k0, nbk, st, -1.0, 0))) return rc;
     }
     if (!w.Sinv) return VGGP_OK;
-    return gemm1(w.X, 1, M, w.X, M, 1, w.Sinv, M, M, M, M, st);       // Sinv = X^T X
+    VgGemmBatch g;                                                     // Sinv = X^T X, X lower triangular: the sum runs over k >= max(i, j)
+    vg_gemm_init(&g);
+    const int i = vg_gemm_add(&g, w.X, 1, M, w.X, M, 1, w.Sinv, M, M, M, M);
+    g.p[i].tri = VG_TRI_A_UPPER_B_LOWER;
+    VG_HIP(vg_gemm_launch(&g, st));
+    return VGGP_OK;
 }
 
 static int dense_chol_inverse(vggp_ctx* c, VgMasked& w, hipStream_t st) {
@@ -347,7 +368,7 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     c->have_masked = false;          // a failed step must not leave an earlier step's state readable (qv_masked / posterior_masked)
     VG_REQUIRE(!(c->desc.flags & VGGP_FLAG_SCATTERED), "vggp_elbo_step_masked: the context was planned for scattered points");
     const long m1 = c->desc.m1, m2 = c->desc.m2, n1 = c->desc.n1, n2 = c->desc.n2, M = m1 * m2;
-    VG_REQUIRE(M <= 8192, "vggp_elbo_step_masked: M = m1*m2 = %ld too large for the dense masked solver (<= 8192)", M);
+    VG_REQUIRE(M <= VGM_MAX_M, "vggp_elbo_step_masked: M = m1*m2 = %ld too large for the dense masked solver (<= %d)", M, VGM_MAX_M);
     VG_REQUIRE(m1 * m1 * n1 < (1L << 31) && m2 * m2 * n2 < (1L << 31) && M * M < (1L << 31) * 4, "masked problem too large");
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
@@ -491,7 +512,7 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
     VG_REQUIRE(c->desc.flags & VGGP_FLAG_SCATTERED, "vggp_elbo_step_scattered: plan the context with VGGP_FLAG_SCATTERED");
     c->have_masked = false;
     const long m1 = c->desc.m1, m2 = c->desc.m2, N = c->desc.n1, M = m1 * m2;
-    VG_REQUIRE(M <= 8192, "vggp_elbo_step_scattered: M = m1*m2 = %ld too large for the dense solver (<= 8192)", M);
+    VG_REQUIRE(M <= VGM_MAX_M, "vggp_elbo_step_scattered: M = m1*m2 = %ld too large for the dense solver (<= %d)", M, VGM_MAX_M);
     VG_REQUIRE(m1 * m1 * N < (1L << 31) && m2 * m2 * N < (1L << 31) && M * M < (1L << 31) * 4, "scattered problem too large");
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
