@@ -501,8 +501,31 @@ def scattered_bench(eng, N=100000, m=32, kind="matern12", steps=10, warmup=3):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     M = m * m
-    return {"points": N, "m_d": m, "M": M, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "elbo_last": e,
-            "assembly_flops": 3 * 2.0 * M * M * N, "assembly_TFLOP/s_if_all_time": 3 * 2.0 * M * M * N / (ms * 1e-3) / 1e12}
+    out = {"points": N, "m_d": m, "M": M, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "elbo_last": e,
+           "assembly_flops": 3 * 2.0 * M * M * N, "assembly_TFLOP/s_if_all_time": 3 * 2.0 * M * M * N / (ms * 1e-3) / 1e12}
+    # SVGP on the same points with trainable inducing coordinates: step + vggp_zgrad_scattered + in-place move
+    z = [np.linspace(0, 1, m), np.linspace(0, 1, m)]
+    eng.plan("matern32", "points", z[0], X[:, 0].copy(), "matern32", "points", z[1], X[:, 1].copy(), scattered=True)
+    oz = [Adam(z[0].copy(), lr=1e-4), Adam(z[1].copy(), lr=1e-4)]
+
+    def one_z():
+        raw = opt.x
+        e, gr, info = eng.elbo_step_scattered(yd, yy, theta_from_raw(raw.copy()))
+        g1, g2 = eng.zgrad_scattered(yd)
+        opt.step(-(gr / (1.0 + np.exp(-raw))))
+        for d, g in enumerate((g1, g2)):
+            oz[d].step(-g.cpu().numpy())
+            eng.set_inducing(d, oz[d].x)
+
+    for _ in range(2):
+        one_z()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        one_z()
+    torch.cuda.synchronize()
+    out["svgp_train_z_ms_per_iteration"] = (time.perf_counter() - t0) / 5 * 1e3
+    return out
 
 
 def factor_build_bench(eng, n=8192, reps=5):

@@ -214,6 +214,12 @@ int vggp_zgrad(vggp_ctx* ctx, const double* Y, double* gz1, double* gz2, void* s
 int vggp_elbo_step_scattered(vggp_ctx* ctx, const double* y, double yy, const double theta[5], double* elbo_out,
                              double grad_out[5], vggp_info* info, void* stream);
 
+/* Gradient of the scattered ELBO w.r.t. the inducing coordinates (what the reference obtains from autograd through _elbo()
+ * into the Z Parameter of its SVGP classes, kronecker_structure.py:303-304, when X holds scattered points), after
+ * vggp_elbo_step_scattered on the same y: gz1 [m1], gz2 [m2] (DEVICE; zeros for a dimension that does not use the points
+ * basis).  One more M x M x N product; workspace 2 M N doubles (M N < 2^31).  Single rank. */
+int vggp_zgrad_scattered(vggp_ctx* ctx, const double* y, double* gz1, double* gz2, void* stream);
+
 /* New inducing coordinates z[0..m) (host array) for dimension dim (0 or 1) of a planned context whose basis there is
  * VGGP_BASIS_POINTS, without re-planning: arena, captured graphs and the eigensolver's warm start are kept.  What an optimiser
  * that trains Z (kronecker_structure.py:303-304 registers it as a Parameter) calls between steps.  Read-outs need a new step. */

@@ -689,3 +689,48 @@ def elbo_step_scattered(X: np.ndarray, y: np.ndarray, f1: Factor, f2: Factor, th
     st.elbo = float(elbo)
     st.grad = np.array([ell_grad(1), ell_grad(2), g_s1, g_s2, g_v])
     return st
+
+
+def z_grad_scattered(st: MaskedState, X: np.ndarray, y: np.ndarray, f1: Factor, f2: Factor):
+    """dELBO/dz of elbo_step_scattered for the inducing coordinates of both dimensions -> (g1 [m1], g2 [m2]) (the spec of
+    vggp_zgrad_scattered; the reference gets it from autograd through _elbo(), kronecker_structure.py:249-278, Z being a
+    Parameter of the SVGP classes :303-304).
+
+    With the unit-scale whitened factors B_d = L0_d^-1 A0_d at the points, the ELBO depends on the inducing coordinates only
+    through z_k = b1_k (x) b2_k:  G_B1[:, k] = -rho mat(Sigma~^-1 z_k) b2_k + (s1 s2 / v^2)(y_k - rho b1_k^T A0 b2_k) A0 b2_k
+    + (s1 s2 / v) |b2_k|^2 b1_k  (and the mirror image for dimension 2).  The ELBO is a function of A0^T K0^-1 A0 alone, so
+    Abar = L0^-T G_B and Kbar = -1/2 L0^-T (G_B B^T) L0^-1, contracted with d kappa / d z as in z_grad."""
+    ell1, ell2, s1, s2, v = [float(t) for t in st.theta]
+    X = np.asarray(X, float)
+    y = np.asarray(y, float).reshape(-1)
+    d1, d2 = st.d1, st.d2
+    B1, B2 = d1.B, d2.B
+    m1, m2, N = B1.shape[0], B2.shape[0], len(y)
+    rho = s1 * s2 / v
+    Zt = (B1[:, None, :] * B2[None, :, :]).reshape(m1 * m2, N)
+    U = (st.Sinv @ Zt).reshape(m1, m2, N)
+    u1 = np.einsum("ijk,jk->ik", U, B2)
+    u2 = np.einsum("ijk,ik->jk", U, B1)
+    UB1, UB2 = st.A0 @ B2, st.A0.T @ B1                                  # A0 b2_k (m1 x N), A0^T b1_k (m2 x N)
+    zb = (B1 * UB1).sum(0)
+    w = (s1 * s2 / v ** 2) * (y - rho * zb)
+    nb1, nb2 = (B1 * B1).sum(0), (B2 * B2).sum(0)
+    G1 = -rho * u1 + w[None, :] * UB1 + (s1 * s2 / v) * nb2[None, :] * B1
+    G2 = -rho * u2 + w[None, :] * UB2 + (s1 * s2 / v) * nb1[None, :] * B2
+    out = []
+    for dd, f, ell, G, x in ((d1, f1, ell1, G1, X[:, 0]), (d2, f2, ell2, G2, X[:, 1])):
+        if f.basis != "points":
+            out.append(np.zeros(f.m))
+            continue
+        Abar = sla.solve_triangular(dd.L, G, lower=True, trans="T")
+        Z1 = sla.solve_triangular(dd.L, -0.5 * (G @ dd.B.T), lower=True, trans="T")
+        Kbar = sla.solve_triangular(dd.L, Z1.T, lower=True, trans="T").T
+        K0, dK0, A0, dA0 = Factor(f.basis, f.kind, f.grid, x.copy(), f.f32_kdelta).build(ell)
+        z = np.asarray(f.grid, float)
+        dzx = z[:, None] - x[None, :]
+        dzz = z[:, None] - z[None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tA = np.where(dzx != 0.0, dA0 / dzx, 0.0)
+            tK = np.where(dzz != 0.0, dK0 / dzz, 0.0)
+        out.append(-ell * ((Abar * tA).sum(1) + ((Kbar + Kbar.T) * tK).sum(1)))
+    return out[0], out[1]

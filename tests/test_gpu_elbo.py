@@ -677,3 +677,33 @@ def test_readout_masked_equals_full_grid_readout(engine, literal):
     engine.elbo_step_scattered(yd, float(y @ y), th)
     mean2, var2 = engine.readout(C1t, C2t, kd1, kd2, literal=literal, masked=True)
     assert rel(mean2.cpu().numpy(), mean0.cpu().numpy()) < 1e-8 and rel(var2.cpu().numpy(), var0.cpu().numpy()) < 1e-8
+
+
+@pytest.mark.parametrize("kind,tol", [("matern32", 1e-6), ("matern12", 1e-6), ("rbf", 1e-4)])
+def test_zgrad_scattered_vs_oracle(engine, kind, tol):
+    """vggp_zgrad_scattered (gradient of the scattered ELBO w.r.t. the inducing coordinates: what autograd gives the reference's
+    SVGP classes on along-track data) against oracle/kron.py z_grad_scattered, which matches central differences of the
+    scattered oracle (CPU suite); then vggp_set_inducing moves Z and both track the oracle again."""
+    rng = np.random.default_rng(8)
+    N, m1, m2 = 5000, 12, 10
+    X = rng.uniform(0, 1, (N, 2))
+    y = np.sin(5 * X[:, 0]) * np.cos(4 * X[:, 1]) + 0.05 * rng.normal(size=N)
+    z1 = np.linspace(0.03, 0.97, m1) + rng.uniform(-0.02, 0.02, m1)
+    z2 = np.linspace(0.03, 0.97, m2) + rng.uniform(-0.02, 0.02, m2)
+    th = np.array([0.21, 0.27, 1.2, 0.9, 0.02])
+    yd = torch.tensor(y, device=DEV)
+    engine.plan(kind, "points", z1, X[:, 0].copy(), kind, "points", z2, X[:, 1].copy(), scattered=True)
+    for rep in range(2):
+        f1, f2 = Kr.Factor("points", kind, z1, X[:, 0].copy()), Kr.Factor("points", kind, z2, X[:, 1].copy())
+        ref = Kr.elbo_step_scattered(X, y, f1, f2, th)
+        r1, r2 = Kr.z_grad_scattered(ref, X, y, f1, f2)
+        elbo, grad, _ = engine.elbo_step_scattered(yd, float(y @ y), th)
+        g1, g2 = engine.zgrad_scattered(yd)
+        assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo)
+        assert rel(g1.cpu().numpy(), r1) < tol and rel(g2.cpu().numpy(), r2) < tol, (rep, rel(g1.cpu().numpy(), r1), rel(g2.cpu().numpy(), r2))
+        z1 = z1 + 1e-3 * np.sign(r1)
+        z2 = z2 + 1e-3 * np.sign(r2)
+        engine.set_inducing(0, z1)
+        engine.set_inducing(1, z2)
+    with pytest.raises(Exception):
+        engine.zgrad_scattered(yd)                     # set_inducing invalidated the state: a new step first

@@ -513,3 +513,46 @@ def test_scattered_inputs_model_matches_dense_oracle(engine):
         opt.step()
         first = loss.item() if first is None else first
     assert loss.item() < first
+
+
+@pytest.mark.parametrize("data", ["scattered", "holes"])
+def test_svgp_trainable_inducing_points_on_incomplete_data(engine, data):
+    """Matern32SVGP with its default trainable Z on scattered points and on a grid with holes (treated as its observed points):
+    Z.grad (vggp_zgrad_scattered) and the hyper-parameter gradients against autograd through the literal dense restatement on
+    the same points, then an Adam loop that moves everything."""
+    import variational_gridded_gaussian_processes_amd.models as M
+    rng = np.random.default_rng(6)
+    if data == "scattered":
+        N = 350
+        X = rng.uniform(0, 1, (N, 2))
+        y = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.05 * rng.standard_normal(N)
+    else:
+        X, y, x1, x2 = D.gen_grid(20, 17)
+        keep = rng.random(len(y)) > 0.3
+        X, y = X[keep], y[keep]
+    m = 6
+    Z = torch.tensor(np.stack([np.linspace(0.05, 0.95, m) + rng.uniform(-0.03, 0.03, m),
+                               np.linspace(0.05, 0.95, m) + rng.uniform(-0.03, 0.03, m)], axis=1))
+    model = M.Matern32SVGP(torch.tensor(X), torch.tensor(y), Z, engine=engine).to(torch.float64)
+    assert model.Z.requires_grad and model._scattered
+    dm = D.DenseKron(X, y, "points", "matern32", Z[:, 0].clone(), Z[:, 1].clone())
+    dm.grid_1.requires_grad_(True)
+    dm.grid_2.requires_grad_(True)
+    e = model._elbo()
+    e.backward()
+    ed = dm._elbo()
+    ed.backward()
+    want = torch.stack([dm.grid_1.grad, dm.grid_2.grad], dim=1).numpy()
+    assert abs(e.item() - ed.item()) <= 1e-6 * abs(ed.item())
+    assert rel(model.Z.grad.numpy(), want) < 1e-5
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    z0, first = model.Z.detach().clone(), None
+    for it in range(6):
+        opt.zero_grad()
+        loss = -model._elbo()
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+    assert loss.item() < first and (model.Z.detach() - z0).abs().max() > 1e-3
+    p = model.posterior(torch.tensor(rng.uniform(0, 1, (10, 2))))
+    assert torch.isfinite(p.mean).all() and (p.variance > 0).all()

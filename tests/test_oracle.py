@@ -256,6 +256,32 @@ def test_z_grad_matches_central_differences(kind):
 
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern12"])
+def test_z_grad_scattered_matches_central_differences(kind):
+    """oracle/kron.py z_grad_scattered (the spec of vggp_zgrad_scattered) against central differences of the scattered ELBO."""
+    rng = np.random.default_rng(4)
+    N, m1, m2 = 300, 6, 5
+    X = rng.uniform(0, 1, (N, 2))
+    y = np.sin(5 * X[:, 0]) * np.cos(4 * X[:, 1]) + 0.05 * rng.normal(size=N)
+    z1 = np.linspace(0.05, 0.95, m1) + rng.uniform(-0.03, 0.03, m1)      # (irregular, but no near-coincident pair: central
+    z2 = np.linspace(0.05, 0.95, m2) + rng.uniform(-0.03, 0.03, m2)      #  differences through an RBF Kuu of cond 1e10 are noise)
+    th = np.array([0.21, 0.27, 1.2, 0.9, 0.02])
+    mk = lambda za, zb: (Kr.Factor("points", kind, za, X[:, 0].copy()), Kr.Factor("points", kind, zb, X[:, 1].copy()))
+    f1, f2 = mk(z1, z2)
+    g1, g2 = Kr.z_grad_scattered(Kr.elbo_step_scattered(X, y, f1, f2, th), X, y, f1, f2)
+    h = 1e-6
+    for dim, (z, g) in enumerate(((z1, g1), (z2, g2))):
+        fd = np.zeros(len(z))
+        for i in range(len(z)):
+            zp, zm = z.copy(), z.copy()
+            zp[i] += h
+            zm[i] -= h
+            fp = mk(zp, z2) if dim == 0 else mk(z1, zp)
+            fm = mk(zm, z2) if dim == 0 else mk(z1, zm)
+            fd[i] = (Kr.elbo_step_scattered(X, y, *fp, th).elbo - Kr.elbo_step_scattered(X, y, *fm, th).elbo) / (2 * h)
+        assert np.abs(g - fd).max() <= 5e-6 * np.abs(fd).max()
+
+
 @pytest.mark.parametrize("basis,kind,g1,g2", [("b0", "matern12", np.linspace(0, 1, 7), np.linspace(0, 1, 6)),
                                               ("points", "matern32", np.linspace(0, 1, 6), np.linspace(0.05, 0.95, 5)),
                                               ("points", "rbf", np.linspace(0, 1, 5), np.linspace(0, 1, 5))])

@@ -63,6 +63,7 @@ SYMBOLS = {
     "vggp_qv": (_I, [_P, _P, _P, _P]),
     "vggp_qv_cov": (_I, [_P, _P, _P]),
     "vggp_zgrad": (_I, [_P, _P, _P, _P, _P]),
+    "vggp_zgrad_scattered": (_I, [_P, _P, _P, _P, _P]),
     "vggp_set_inducing": (_I, [_P, C.c_int, _P, C.c_int64]),
     "vggp_posterior": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "vggp_readout": (_I, [_P, _P, _I64, _P, _I64, _P, _P, _P, _P, _I, _P]),

@@ -375,13 +375,6 @@ extern "C" int64_t vggp_workspace_bytes(const vggp_ctx* c) { return c ? (int64_t
 // GEMM launch subtracts the contribution of the block rows already solved (L[b, :b] X[:b], all workgroups of the chip, all
 // jobs of the batch) and ONE strip-kernel launch solves the 128 x 128 diagonal blocks (factor staged in LDS).
 // Dinv: inverses of the 16 x 16 diagonal blocks of L, block b16 at Dinv + b16 * dinv_blk, row stride dinv_ld.
-#define VG_TRSM_BLK 128
-struct VgTrsmSpec {
-    const double* L; long ldl;
-    const double* Dinv; long dinv_blk, dinv_ld;
-    double* X; long sk, sc, ncols;
-    long m; int trans;
-};
 static int trsm_batch(const VgTrsmSpec* sp, int n, hipStream_t st) {
     int max_nblk = 0;
     for (int j = 0; j < n; ++j) max_nblk = std::max(max_nblk, (int)((sp[j].m + VG_TRSM_BLK - 1) / VG_TRSM_BLK));
@@ -1733,6 +1726,8 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
 // ---------------------------------------------------------------------------------
 // Gradient of the ELBO with respect to the inducing-point coordinates (SVGP's trainable Z: kronecker_structure.py:303-304
 // registers Z as a Parameter and autograd differentiates through kernel(Z), kernel(Z, x)).  Spec: oracle/kron.py z_grad.
+int vg_trsm_batch(const VgTrsmSpec* sp, int n, hipStream_t st) { return trsm_batch(sp, n, st); }      // (masked.hip: vggp_zgrad_scattered)
+
 // The analytic lengthscale gradient is linear in the perturbation (dK, dA) it is fed, dELBO = <W_M, L^-1 dK L^-T> + <W_V, L^-1 dA>,
 // so Kbar = L^-T W_M L^-1 and Abar = L^-T W_V are the sensitivities, and for a stationary kernel
 // d kappa(z_i, x) / d z_i = -(d kappa / d ell) ell / (z_i - x): the derivative factors dA0, dK0 of the step are reused.

@@ -119,3 +119,12 @@ int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st);
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false, bool fused = false,
                         bool apply_ns = false);
 void vg_masked_free(vggp_ctx* c);
+// batch of triangular solves, each in place on its X (api.hip trsm_batch: element (row k, column c) at X[k * sk + c * sc])
+#define VG_TRSM_BLK 128
+struct VgTrsmSpec {
+    const double* L; long ldl;
+    const double* Dinv; long dinv_blk, dinv_ld;
+    double* X; long sk, sc, ncols;
+    long m; int trans;
+};
+int vg_trsm_batch(const VgTrsmSpec* sp, int n, hipStream_t st);

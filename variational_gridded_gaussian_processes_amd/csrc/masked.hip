@@ -628,6 +628,100 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
     return VGGP_OK;
 }
 
+// ---- gradient of the scattered ELBO w.r.t. the inducing coordinates (SVGP's trainable Z on along-track data) -------------------
+// G_B1[i1][k] = -rho sum_i2 U[(i1,i2)][k] B2[i2][k] + w_k UB1[i1][k] + (s1 s2 / v) |b2_k|^2 B1[i1][k],  U = Sigma~^-1 (B1 kr B2),
+// w_k = (s1 s2 / v^2)(y_k - rho b1_k^T A0 b2_k), UB1 = A0 B2 (dimension 2: the mirror image, `other` = B1, UBs = A0^T B1).
+__global__ void vgm_zg_kernel(const double* U, const double* Bs, const double* Bo, const double* UBs, const double* y, const double* zb,
+                              const double* nbo, const double* theta, int ms, int mo, long N, int dim, double* G) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)ms * N) return;
+    const int i = (int)(idx / N);
+    const long k = idx - (long)i * N;
+    const double s12 = theta[2] * theta[3], v = theta[4], rho = s12 / v;
+    double u = 0.0;
+    if (dim == 0) for (int j = 0; j < mo; ++j) u += U[((long)i * mo + j) * N + k] * Bo[(long)j * N + k];       // rows (i, j) of U
+    else          for (int j = 0; j < mo; ++j) u += U[((long)j * ms + i) * N + k] * Bo[(long)j * N + k];       // rows (j, i)
+    G[idx] = -rho * u + (s12 / (v * v)) * (y[k] - rho * zb[k]) * UBs[idx] + (s12 / v) * nbo[k] * Bs[idx];
+}
+__global__ void vgm_scal_kernel(double* x, long n, double a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= a;
+}
+
+// dELBO/dz after vggp_elbo_step_scattered on the same y (oracle/kron.py z_grad_scattered; the reference: autograd through _elbo()
+// into the Z Parameter of its SVGP classes, kronecker_structure.py:303-304).  The ELBO is a function of A0^T K0^-1 A0 alone, so
+// Abar = L0^-T G_B and Kbar = -1/2 L0^-T (G_B B^T) L0^-1; the contraction with d kappa / d z is vggp_zgrad's.  One extra
+// M x M x N product (U) on top of the step's three; workspace 2 M N doubles.  Single rank.
+extern "C" int vggp_zgrad_scattered(vggp_ctx* c, const double* y, double* gz1, double* gz2, void* stream) {
+    if (!c || !c->have_masked || !c->masked || !(c->desc.flags & VGGP_FLAG_SCATTERED)) {
+        vg_set_error("vggp_zgrad_scattered: no finished scattered step");
+        return VGGP_ESTATE;
+    }
+    VG_REQUIRE(y && gz1 && gz2, "vggp_zgrad_scattered: null argument");
+    if (c->n_ranks > 1 || c->comm || c->cb) { vg_set_error("vggp_zgrad_scattered: point-sharded contexts are not supported yet"); return VGGP_ESTATE; }
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
+    const long m1 = w.m1, m2 = w.m2, M = w.M, N = c->desc.n1;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const bool pts[2] = {d1.basis == VGGP_BASIS_POINTS, d2.basis == VGGP_BASIS_POINTS};
+    if (!pts[0]) VG_HIP(hipMemsetAsync(gz1, 0, sizeof(double) * m1, st));
+    if (!pts[1]) VG_HIP(hipMemsetAsync(gz2, 0, sizeof(double) * m2, st));
+    if (!pts[0] && !pts[1]) return VGGP_OK;
+    VG_REQUIRE(M * N < (1L << 31), "vggp_zgrad_scattered: M N = %ld too large", M * N);
+    int rc = vg_ensure_misc(c, sizeof(double) * (size_t)(2 * M * N + 2 * (m1 + m2) * N + 3 * N + m1 * m1 + m2 * m2 + 64));
+    if (rc) return rc;
+    double* p = reinterpret_cast<double*>(c->misc);
+    double *Zt = p; p += M * N;
+    double *U = p; p += M * N;
+    double *G[2], *UBs[2];
+    G[0] = p; p += m1 * N; G[1] = p; p += m2 * N; UBs[0] = p; p += m1 * N; UBs[1] = p; p += m2 * N;
+    double *zb = p; p += N;
+    double *nb1 = p; p += N;
+    double *nb2 = p; p += N;
+    double* WM[2] = {p, p + m1 * m1};
+    const double *B1 = d1.BV, *B2 = d2.BV;
+    VGM_LAUNCH1D(vgm_pairprod_kernel, M * N, st, B1, B2, (int)m1, (int)m2, N, Zt);
+    VG_HIP(hipGetLastError());
+    if ((rc = gemm1(w.Sinv, M, 1, Zt, N, 1, U, (int)N, (int)M, (int)N, (int)M, st))) return rc;
+    if ((rc = gemm1(w.a0, m2, 1, B2, N, 1, UBs[0], (int)N, (int)m1, (int)N, (int)m2, st))) return rc;       // A0 B2
+    if ((rc = gemm1(w.a0, 1, m2, B1, N, 1, UBs[1], (int)N, (int)m2, (int)N, (int)m1, st))) return rc;       // A0^T B1
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B1, UBs[0], (int)m1, N, zb);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B1, B1, (int)m1, N, nb1);
+    VGM_LAUNCH1D(vgm_coldot_kernel, N, st, B2, B2, (int)m2, N, nb2);
+    VGM_LAUNCH1D(vgm_zg_kernel, m1 * N, st, U, B1, B2, UBs[0], y, zb, nb2, c->theta, (int)m1, (int)m2, N, 0, G[0]);
+    VGM_LAUNCH1D(vgm_zg_kernel, m2 * N, st, U, B2, B1, UBs[1], y, zb, nb1, c->theta, (int)m2, (int)m1, N, 1, G[1]);
+    VG_HIP(hipGetLastError());
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        if (!pts[k]) continue;
+        if ((rc = gemm_longk(G[k], N, 1, d.BV, 1, N, WM[k], d.m, d.m, (int)N, w.T, st))) return rc;          // G_B B^T
+        VGM_LAUNCH1D(vgm_scal_kernel, (long)d.m * d.m, st, WM[k], (long)d.m * d.m, -0.5);
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        VgTrsmSpec q[4];
+        int nq = 0;
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            if (!pts[k]) continue;
+            const bool dv = d.m <= VG_TRSM_BLK && d.Dinv0 && c->dinv_valid;
+            const double* dp = dv ? d.Dinv0 : d.Linv0;
+            const long blk = dv ? 256 : 16L * d.m + 16, dld = dv ? 16 : d.m;
+            if (pass == 0) {
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dp, blk, dld, G[k], N, 1, N, d.m, 1};                       // Abar = L0^-T G_B
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dp, blk, dld, WM[k], d.m, 1, d.m, d.m, 1};                  // L0^-T W_M
+            } else {
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dp, blk, dld, WM[k], 1, d.m, d.m, d.m, 1};                  // (.) L0^-1
+            }
+        }
+        if ((rc = vg_trsm_batch(q, nq, st))) return rc;
+    }
+    if (pts[0]) VG_HIP(vg_zdot_launch(c->theta, 0, d1.grid, d1.x, (int)m1, N, G[0], d1.AD + m1 * N, WM[0], d1.dK0, gz1, st));
+    if (pts[1]) VG_HIP(vg_zdot_launch(c->theta, 1, d2.grid, d2.x, (int)m2, N, G[1], d2.AD + m2 * N, WM[1], d2.dK0, gz2, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}
+
 // q(v) of the last masked step: mean = (s1 s2 / v) L1 A0 L2^T, diag cov = s1 s2 rowdot((L1 (x) L2) Sinv, L1 (x) L2)
 extern "C" int vggp_qv_masked(vggp_ctx* c, double* mean, double* var, void* stream) {
     if (!c || !c->have_masked || !c->masked) { vg_set_error("vggp_qv_masked: no finished masked step"); return VGGP_ESTATE; }

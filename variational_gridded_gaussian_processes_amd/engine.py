@@ -267,6 +267,13 @@ class Engine:
         check(self.lib.vggp_zgrad(self._h, _ptr(Y), _ptr(g1), _ptr(g2), _stream(self.device)))
         return g1, g2
 
+    def zgrad_scattered(self, y: torch.Tensor):
+        """d ELBO / d z of the last elbo_step_scattered(y, ...) -> (g1 [m1], g2 [m2]) device tensors."""
+        g1 = torch.empty(self.m1, dtype=torch.float64, device=self.device)
+        g2 = torch.empty(self.m2, dtype=torch.float64, device=self.device)
+        check(self.lib.vggp_zgrad_scattered(self._h, _ptr(y), _ptr(g1), _ptr(g2), _stream(self.device)))
+        return g1, g2
+
     def qv_cov_masked(self) -> torch.Tensor:
         M = self.m1 * self.m2
         cov = torch.empty(M, M, dtype=torch.float64, device=self.device)

@@ -143,7 +143,7 @@ class _ElboFunction(torch.autograd.Function):
         if Z is not None and Z.requires_grad:
             # trainable inducing points (the reference registers Z as a Parameter, kronecker_structure.py:303-304, and autograd
             # reaches it through kernel(Z)): analytic gradient from the engine's resident state (vggp_zgrad)
-            g1, g2 = model._engine.zgrad(model._Y)
+            g1, g2 = model._engine.zgrad_scattered(model._Y) if model._scattered else model._engine.zgrad(model._Y)
             cols = [g1] if Z.shape[1] == 1 else [g1, g2]
             gz = torch.stack(cols, dim=1).to(dtype=Z.dtype, device=Z.device)
         ctx.save_for_backward(torch.as_tensor(grad, dtype=theta.dtype, device=theta.device), gz)
@@ -220,6 +220,19 @@ class KroneckerStructure(torch.nn.Module):
         else:
             self._Y = yd.reshape(n2, n1).contiguous()
         self._yy = float((yd * yd).sum().item()) if self._scattered else self._engine.sumsq(self._Y)
+
+    def _as_scattered(self):
+        """Switch a masked-grid model to the scattered representation of the same observations (one coordinate pair per point):
+        the step with a Z-gradient on incomplete data is vggp_zgrad_scattered."""
+        if self._scattered or not self._masked:
+            return
+        Xn = self.train_inputs[0].detach().cpu().numpy().astype(np.float64)
+        yd = torch.as_tensor(self.train_targets, dtype=torch.float64).reshape(-1).to(self._engine.device)
+        self._x1, self._x2 = Xn[:, 0].copy(), Xn[:, 1].copy()
+        self._scattered, self._Y, self._nobs = True, yd.contiguous(), float(yd.numel())
+        self._yy = float((yd * yd).sum().item())
+        self._W = None
+        self._planned = False
 
     # subclasses provide (basis, grid_1, grid_2)
     def _basis(self) -> Tuple[str, np.ndarray, np.ndarray]:
@@ -580,12 +593,15 @@ class Matern12SVGP(KroneckerStructure):
     """kronecker_structure.py:287-338: Z (m, 2) holds the per-dimension inducing coordinates; the inducing set
     is cartesian_prod(Z[:,0], Z[:,1]) (:336), so Kuu = kron(K1(Z[:,0]), K2(Z[:,1])) (:318-321).
     Z is a trainable Parameter as in the reference (:303-304): `_elbo()` carries its analytic gradient (vggp_zgrad) unless
-    `train_z=False`.  Moved inducing points reach the engine through vggp_set_inducing (no re-plan: graphs and warm start stay).  On a masked
-    grid (X a subset of a cartesian grid) Z stays fixed: the masked step has no Z-gradient yet."""
+    `train_z=False`.  Moved inducing points reach the engine through vggp_set_inducing (no re-plan: graphs and warm start stay).  On
+    incomplete data (scattered points, or a grid with holes, which is then treated as its observed points) the gradient is
+    vggp_zgrad_scattered's."""
 
     def __init__(self, X, y, Z: torch.Tensor, train_z: bool = True, **kw):
         super().__init__(X, y, **kw)
-        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=bool(train_z) and not self._masked)      # (masked / scattered steps: fixed Z)
+        self.Z = torch.nn.Parameter(torch.as_tensor(Z, dtype=torch.float64).clone(), requires_grad=bool(train_z))
+        if train_z:
+            self._as_scattered()
 
     def _elbo(self) -> torch.Tensor:
         return _ElboFunction.apply(self._theta(), self, self.Z)
