@@ -143,7 +143,7 @@ class _ElboFunction(torch.autograd.Function):
         if Z is not None and Z.requires_grad:
             # trainable inducing points (the reference registers Z as a Parameter, kronecker_structure.py:303-304, and autograd
             # reaches it through kernel(Z)): analytic gradient from the engine's resident state (vggp_zgrad)
-            g1, g2 = model._engine.zgrad_scattered(model._Y) if model._scattered else model._engine.zgrad(model._Y)
+            g1, g2 = model._engine.zgrad_scattered(model._Y) if getattr(model, "_scattered", False) else model._engine.zgrad(model._Y)
             cols = [g1] if Z.shape[1] == 1 else [g1, g2]
             gz = torch.stack(cols, dim=1).to(dtype=Z.dtype, device=Z.device)
         ctx.save_for_backward(torch.as_tensor(grad, dtype=theta.dtype, device=theta.device), gz)
