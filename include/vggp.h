@@ -202,7 +202,7 @@ int vggp_qv_cov(vggp_ctx* ctx, double* cov, void* stream);
  * gz1 [m1], gz2 [m2] (device): d ELBO / d z_d[i]; zeros for a dimension whose basis is not VGGP_BASIS_POINTS.
  * Analytic (no autograd): the sensitivities Kbar = L^-T W_M L^-1, Abar = L^-T W_V follow from the linearity of the lengthscale
  * gradient in (dK, dA), and d kappa(z, x)/dz = -(d kappa/d ell) ell / (z - x) for the stationary kernels.
- * Single-rank contexts only (VGGP_ESTATE otherwise). */
+ * Row-sharded contexts: Y is the rank's slab; the parts of the ranks' rows are summed by one all-reduce of m1 + m2 doubles. */
 int vggp_zgrad(vggp_ctx* ctx, const double* Y, double* gz1, double* gz2, void* stream);
 
 /* Collapsed ELBO and gradient for N SCATTERED observations (along-track points: the reference's _elbo(), kronecker_structure.py
@@ -217,7 +217,8 @@ int vggp_elbo_step_scattered(vggp_ctx* ctx, const double* y, double yy, const do
 /* Gradient of the scattered ELBO w.r.t. the inducing coordinates (what the reference obtains from autograd through _elbo()
  * into the Z Parameter of its SVGP classes, kronecker_structure.py:303-304, when X holds scattered points), after
  * vggp_elbo_step_scattered on the same y: gz1 [m1], gz2 [m2] (DEVICE; zeros for a dimension that does not use the points
- * basis).  One more M x M x N product; workspace 2 M N doubles (M N < 2^31).  Single rank. */
+ * basis).  One more M x M x N product; workspace 2 M N doubles (M N < 2^31).  Point-sharded contexts: the parts of the ranks'
+ * points are summed by one all-reduce of m1 + m2 doubles. */
 int vggp_zgrad_scattered(vggp_ctx* ctx, const double* y, double* gz1, double* gz2, void* stream);
 
 /* New inducing coordinates z[0..m) (host array) for dimension dim (0 or 1) of a planned context whose basis there is

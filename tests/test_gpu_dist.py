@@ -311,7 +311,8 @@ def _scattered_worker(rank, world, port, q):
             th = np.array(THETA) * (1.0 + 0.02 * k)
             out.append(eng.elbo_step_scattered(yd, float(y @ y), th)[:2])
         mean, var = eng.qv_masked()
-        q.put((rank, out, mean.cpu().numpy(), var.cpu().numpy()))
+        gz1, gz2 = eng.zgrad_scattered(yd)
+        q.put((rank, out, mean.cpu().numpy(), var.cpu().numpy(), gz1.cpu().numpy(), gz2.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -344,5 +345,61 @@ def test_scattered_step_sharded_over_points(engine, world):
             assert np.abs(g - ref.grad).max() <= 1e-7 * np.abs(ref.grad).max(), (k, rank)
         assert all(r[1][k][0] == res[0][1][k][0] for r in res)
     rm, rv = Kr.q_v_masked(ref)
-    for _, _, mean, var in res:
+    z1, z2 = Kr.z_grad_scattered(ref, X, y, f1, f2)          # Z-gradient: local parts + one all-reduce of m1 + m2 doubles
+    for _, _, mean, var, gz1, gz2 in res:
         assert np.abs(mean - rm).max() <= 1e-7 * np.abs(rm).max() and np.abs(var - rv).max() <= 1e-7 * np.abs(rv).max()
+        assert np.abs(gz1 - z1).max() <= 1e-6 * np.abs(z1).max() and np.abs(gz2 - z2).max() <= 1e-6 * np.abs(z2).max()
+
+
+# ---- Z-gradient of a row-sharded full-grid job ---------------------------------------------------------------------------------
+def _zgrad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import dense as D
+    from variational_gridded_gaussian_processes_amd.sharded import ShardedStep, make_engine, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, x1, x2 = D.gen_grid(N1, N2)
+        rows = shard_rows(N2, rank, world)
+        rng = np.random.default_rng(3)
+        z1 = np.linspace(0.03, 0.97, M1) + rng.uniform(-0.02, 0.02, M1)
+        z2 = np.linspace(0.03, 0.97, M2) + rng.uniform(-0.02, 0.02, M2)
+        eng = make_engine(0, transport="gloo")
+        eng.plan("matern32", "points", z1, x1, "matern32", "points", z2, x2[rows], n_total=N1 * N2)
+        Y = torch.tensor(y.reshape(N2, N1)[rows], device="cuda:0")
+        sh = ShardedStep(eng)
+        e, g, info = sh.step(Y, sh.sumsq_total(Y), np.array(THETA))
+        gz1, gz2 = eng.zgrad(Y)
+        q.put((rank, e, gz1.cpu().numpy(), gz2.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_zgrad_of_a_row_sharded_job(engine, world):
+    """vggp_zgrad on an n_ranks > 1 context: each rank contracts the observations of its rows, the terms that only involve
+    replicated state are added by rank 0, ONE all-reduce of m1 + m2 doubles; every rank equals oracle z_grad on the full grid."""
+    from oracle import dense as D, kron as Kr
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 1000) + world
+    procs = [ctx.Process(target=_zgrad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    X, y, x1, x2 = D.gen_grid(N1, N2)
+    rng = np.random.default_rng(3)
+    z1 = np.linspace(0.03, 0.97, M1) + rng.uniform(-0.02, 0.02, M1)
+    z2 = np.linspace(0.03, 0.97, M2) + rng.uniform(-0.02, 0.02, M2)
+    f1, f2 = Kr.Factor("points", "matern32", z1, x1), Kr.Factor("points", "matern32", z2, x2)
+    Y = y.reshape(N2, N1)
+    ref = Kr.elbo_step(Y, f1, f2, np.array(THETA))
+    r1, r2 = Kr.z_grad(ref, f1, f2, Y)
+    for rank, e, gz1, gz2 in res:
+        assert abs(e - ref.elbo) <= 1e-9 * abs(ref.elbo)
+        assert np.abs(gz1 - r1).max() <= 1e-6 * np.abs(r1).max() and np.abs(gz2 - r2).max() <= 1e-6 * np.abs(r2).max(), rank

@@ -707,3 +707,41 @@ def test_zgrad_scattered_vs_oracle(engine, kind, tol):
         engine.set_inducing(1, z2)
     with pytest.raises(Exception):
         engine.zgrad_scattered(yd)                     # set_inducing invalidated the state: a new step first
+
+
+def test_error_paths_of_the_masked_and_scattered_entries(engine):
+    """Error behaviour at the C-ABI: read-outs and gradients refuse to run without the step whose state they read, steps refuse
+    a context planned for the other data layout, and a failed call leaves a message behind (vggp_last_error)."""
+    from variational_gridded_gaussian_processes_amd import VggpError
+    from variational_gridded_gaussian_processes_amd import _lib
+    n, m = 24, 6
+    X, y, x1, x2 = D.gen_grid(n, n)
+    g = np.linspace(0, 1, m)
+    th = [0.2, 0.3, 1.0, 0.8, 0.01]
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    yd = torch.tensor(y, device=DEV)
+    C = torch.tensor(Kr.cross_b0(Kr.Factor("points", "matern12", g, x1), np.linspace(0, 1, 5), th[0])[0])
+    kd = torch.ones(4, dtype=torch.float64)
+
+    def code(fn):
+        with pytest.raises(VggpError) as ei:
+            fn()
+        assert str(ei.value)                    # the message of vggp_last_error travels with the exception
+        return ei.value.code
+
+    engine.plan("matern12", "points", g, x1, "matern12", "points", g, x2)
+    assert code(lambda: engine.readout(C, C, kd, kd, masked=True)) == _lib.VGGP_ESTATE          # no masked step yet
+    assert code(lambda: engine.qv_masked()) == _lib.VGGP_ESTATE
+    assert code(lambda: engine.zgrad_scattered(yd)) == _lib.VGGP_ESTATE                        # not a scattered context
+    assert code(lambda: engine.elbo_step_scattered(yd[:n].contiguous(), 1.0, th)) != 0           # grid plan, scattered step
+    engine.elbo_step(Y, engine.sumsq(Y), th)
+    assert code(lambda: engine.readout(C, C, kd, kd, masked=True)) == _lib.VGGP_ESTATE          # a full-grid step is no masked state
+    engine.plan("matern12", "points", g, X[:, 0].copy(), "matern12", "points", g, X[:, 1].copy(), scattered=True)
+    assert code(lambda: engine.zgrad_scattered(yd)) == _lib.VGGP_ESTATE                        # planned, but no step yet
+    Yb = torch.zeros(n * n, n * n, dtype=torch.float64, device=DEV)        # (the shape a grid step would want from this plan)
+    assert code(lambda: engine.elbo_step_masked(Yb, torch.ones_like(Yb), float(n * n), 1.0, th)) != 0
+    assert code(lambda: engine.elbo_step(Yb, 1.0, th)) != 0
+    assert code(lambda: engine.elbo_step_scattered(yd, float(y @ y), [0.2, 0.3, -1.0, 0.8, 0.01])) != 0      # theta must be positive
+    engine.elbo_step_scattered(yd, float(y @ y), th)
+    g1, g2 = engine.zgrad_scattered(yd)
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()

@@ -1732,11 +1732,15 @@ int vg_trsm_batch(const VgTrsmSpec* sp, int n, hipStream_t st) { return trsm_bat
 // so Kbar = L^-T W_M L^-1 and Abar = L^-T W_V are the sensitivities, and for a stationary kernel
 // d kappa(z_i, x) / d z_i = -(d kappa / d ell) ell / (z_i - x): the derivative factors dA0, dK0 of the step are reused.
 // Uses the resident state of the last vggp_elbo_step on the same Y (warm-basis accuracy, like the lengthscale gradient); one
-// extra pass over Y (B1 Y^T), ~25 small launches.  Single rank only.
+// extra pass over Y (B1 Y^T), ~25 small launches.
 extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2, void* stream) {
     if (!c || !c->have_step) { vg_set_error("vggp_zgrad: no finished ELBO step"); return VGGP_ESTATE; }
     VG_REQUIRE(Y && gz1 && gz2, "vggp_zgrad: null argument");
-    if (c->n_ranks > 1 || c->comm || c->cb) { vg_set_error("vggp_zgrad: row-sharded contexts are not supported yet"); return VGGP_ESTATE; }
+    // Row-sharded job: every term of g is a sum over observations, so each rank forms the part of ITS rows -- the columns of dimension
+    // 2 it owns, and for dimension 1 (whose n1 columns every rank holds) the projection term through its rows of Y -- while the terms
+    // that only involve replicated state (Kbar, and s1 W_H B1 of dimension 1) are added by rank 0 alone; ONE all-reduce of m1 + m2 doubles.
+    const bool multi = c->n_ranks > 1 || c->comm || c->cb;
+    const bool lead = !multi || c->rank == 0;
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
@@ -1748,7 +1752,7 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
     const double s1 = c->h_theta[2], s2 = c->h_theta[3], v = c->h_theta[4];
     // workspace
     const long mm1 = m1 * m1, mm2 = m2 * m2, m12 = m1 * m2;
-    const size_t need = sizeof(double) * (size_t)(6 * mm1 + 6 * mm2 + 2 * m12 + m1 * n1 + m2 * n2 + m1 * n2);
+    const size_t need = sizeof(double) * (size_t)(6 * mm1 + 6 * mm2 + 2 * m12 + m1 * n1 + m2 * n2 + m1 * n2 + m1 + m2);
     int rc = vg_ensure_misc(c, need);
     if (rc) return rc;
     double* w = reinterpret_cast<double*>(c->misc);
@@ -1760,7 +1764,8 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
     double* U = w; w += m12;
     double* T1 = w; w += m12;
     double* WV[2] = {w, w + m1 * n1}; w += m1 * n1 + m2 * n2;
-    double* R1 = w;
+    double* R1 = w; w += m1 * n2;
+    double* gzbuf = w;                                   // [m1 + m2]: the all-reduce buffer of a row-sharded job
     VgGemmBatch g;
     // 1. the four beta Gram matrices
     vg_gemm_init(&g);
@@ -1786,7 +1791,7 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
     vg_gemm_init(&g);
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
-        vg_gemm_add(&g, d.Qt, 1, d.m, TA[k], d.m, 1, WE[k], d.m, d.m, d.m, d.m);       // W_M -> WE
+        vg_gemm_add(&g, d.Qt, 1, d.m, TA[k], d.m, 1, WE[k], d.m, d.m, d.m, d.m, 1, 0, 1, 0, lead ? 1.0 : 0.0);       // W_M -> WE (replicated: rank 0 only)
         vg_gemm_add(&g, d.Qt, 1, d.m, TB[k], d.m, 1, WF[k], d.m, d.m, d.m, d.m);       // W_H -> WF
     }
     vg_gemm_add(&g, d1.Qt, 1, m1, U, m2, 1, T1, (int)m2, (int)m1, (int)m2, (int)m1);
@@ -1796,7 +1801,7 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
         if (!pts[k]) continue;
-        vg_gemm_add(&g, WF[k], d.m, 1, d.BV, d.n, 1, WV[k], d.n, d.m, d.n, d.m, 1, 0, 1, 0, k ? s2 : s1);
+        vg_gemm_add(&g, WF[k], d.m, 1, d.BV, d.n, 1, WV[k], d.n, d.m, d.n, d.m, 1, 0, 1, 0, k ? s2 : (lead ? s1 : 0.0));       // (dimension 1: replicated)
     }
     VG_HIP(vg_gemm_launch(&g, st));
     vg_gemm_init(&g);
@@ -1831,8 +1836,15 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
         if ((rc = trsm_batch(q, nq, st))) return rc;
     }
     // 6. contraction with d kappa / d z
-    if (pts[0]) VG_HIP(vg_zdot_launch(c->theta, 0, d1.grid, d1.x, (int)m1, n1, WV[0], d1.AD + m1 * n1, WE[0], d1.dK0, gz1, st));
-    if (pts[1]) VG_HIP(vg_zdot_launch(c->theta, 1, d2.grid, d2.x, (int)m2, n2, WV[1], d2.AD + m2 * n2, WE[1], d2.dK0, gz2, st));
+    double *o1 = multi ? gzbuf : gz1, *o2 = multi ? gzbuf + m1 : gz2;
+    if (multi) VG_HIP(hipMemsetAsync(gzbuf, 0, sizeof(double) * (m1 + m2), st));
+    if (pts[0]) VG_HIP(vg_zdot_launch(c->theta, 0, d1.grid, d1.x, (int)m1, n1, WV[0], d1.AD + m1 * n1, WE[0], d1.dK0, o1, st));
+    if (pts[1]) VG_HIP(vg_zdot_launch(c->theta, 1, d2.grid, d2.x, (int)m2, n2, WV[1], d2.AD + m2 * n2, WE[1], d2.dK0, o2, st));
+    if (multi) {
+        if ((rc = vg_allreduce(c, gzbuf, m1 + m2, st))) return rc;
+        VG_HIP(hipMemcpyAsync(gz1, gzbuf, sizeof(double) * m1, hipMemcpyDeviceToDevice, st));
+        VG_HIP(hipMemcpyAsync(gz2, gzbuf + m1, sizeof(double) * m2, hipMemcpyDeviceToDevice, st));
+    }
     VG_HIP(hipStreamSynchronize(st));
     return VGGP_OK;
 }

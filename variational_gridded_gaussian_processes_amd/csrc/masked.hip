@@ -651,14 +651,16 @@ __global__ void vgm_scal_kernel(double* x, long n, double a) {
 // dELBO/dz after vggp_elbo_step_scattered on the same y (oracle/kron.py z_grad_scattered; the reference: autograd through _elbo()
 // into the Z Parameter of its SVGP classes, kronecker_structure.py:303-304).  The ELBO is a function of A0^T K0^-1 A0 alone, so
 // Abar = L0^-T G_B and Kbar = -1/2 L0^-T (G_B B^T) L0^-1; the contraction with d kappa / d z is vggp_zgrad's.  One extra
-// M x M x N product (U) on top of the step's three; workspace 2 M N doubles.  Single rank.
+// M x M x N product (U) on top of the step's three; workspace 2 M N doubles.
 extern "C" int vggp_zgrad_scattered(vggp_ctx* c, const double* y, double* gz1, double* gz2, void* stream) {
     if (!c || !c->have_masked || !c->masked || !(c->desc.flags & VGGP_FLAG_SCATTERED)) {
         vg_set_error("vggp_zgrad_scattered: no finished scattered step");
         return VGGP_ESTATE;
     }
     VG_REQUIRE(y && gz1 && gz2, "vggp_zgrad_scattered: null argument");
-    if (c->n_ranks > 1 || c->comm || c->cb) { vg_set_error("vggp_zgrad_scattered: point-sharded contexts are not supported yet"); return VGGP_ESTATE; }
+    // point-sharded job: every term is a sum over points (Kbar through G_B B^T), so each rank contracts its own points and ONE
+    // all-reduce of m1 + m2 doubles adds the parts
+    const bool multi = c->n_ranks > 1 || c->comm || c->cb;
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
@@ -669,7 +671,7 @@ extern "C" int vggp_zgrad_scattered(vggp_ctx* c, const double* y, double* gz1, d
     if (!pts[1]) VG_HIP(hipMemsetAsync(gz2, 0, sizeof(double) * m2, st));
     if (!pts[0] && !pts[1]) return VGGP_OK;
     VG_REQUIRE(M * N < (1L << 31), "vggp_zgrad_scattered: M N = %ld too large", M * N);
-    int rc = vg_ensure_misc(c, sizeof(double) * (size_t)(2 * M * N + 2 * (m1 + m2) * N + 3 * N + m1 * m1 + m2 * m2 + 64));
+    int rc = vg_ensure_misc(c, sizeof(double) * (size_t)(2 * M * N + 2 * (m1 + m2) * N + 3 * N + m1 * m1 + m2 * m2 + m1 + m2 + 64));
     if (rc) return rc;
     double* p = reinterpret_cast<double*>(c->misc);
     double *Zt = p; p += M * N;
@@ -680,6 +682,7 @@ extern "C" int vggp_zgrad_scattered(vggp_ctx* c, const double* y, double* gz1, d
     double *nb1 = p; p += N;
     double *nb2 = p; p += N;
     double* WM[2] = {p, p + m1 * m1};
+    double* gzbuf = p + m1 * m1 + m2 * m2;
     const double *B1 = d1.BV, *B2 = d2.BV;
     VGM_LAUNCH1D(vgm_pairprod_kernel, M * N, st, B1, B2, (int)m1, (int)m2, N, Zt);
     VG_HIP(hipGetLastError());
@@ -716,8 +719,15 @@ extern "C" int vggp_zgrad_scattered(vggp_ctx* c, const double* y, double* gz1, d
         }
         if ((rc = vg_trsm_batch(q, nq, st))) return rc;
     }
-    if (pts[0]) VG_HIP(vg_zdot_launch(c->theta, 0, d1.grid, d1.x, (int)m1, N, G[0], d1.AD + m1 * N, WM[0], d1.dK0, gz1, st));
-    if (pts[1]) VG_HIP(vg_zdot_launch(c->theta, 1, d2.grid, d2.x, (int)m2, N, G[1], d2.AD + m2 * N, WM[1], d2.dK0, gz2, st));
+    double *o1 = multi ? gzbuf : gz1, *o2 = multi ? gzbuf + m1 : gz2;
+    if (multi) VG_HIP(hipMemsetAsync(gzbuf, 0, sizeof(double) * (m1 + m2), st));
+    if (pts[0]) VG_HIP(vg_zdot_launch(c->theta, 0, d1.grid, d1.x, (int)m1, N, G[0], d1.AD + m1 * N, WM[0], d1.dK0, o1, st));
+    if (pts[1]) VG_HIP(vg_zdot_launch(c->theta, 1, d2.grid, d2.x, (int)m2, N, G[1], d2.AD + m2 * N, WM[1], d2.dK0, o2, st));
+    if (multi) {
+        if ((rc = vg_allreduce(c, gzbuf, m1 + m2, st))) return rc;
+        VG_HIP(hipMemcpyAsync(gz1, gzbuf, sizeof(double) * m1, hipMemcpyDeviceToDevice, st));
+        VG_HIP(hipMemcpyAsync(gz2, gzbuf + m1, sizeof(double) * m2, hipMemcpyDeviceToDevice, st));
+    }
     VG_HIP(hipStreamSynchronize(st));
     return VGGP_OK;
 }
