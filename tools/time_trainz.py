@@ -20,7 +20,7 @@ for it in range(80):
         g1, g2 = eng.zgrad(Y)
     t2 = time.perf_counter()
     a, b = (g1.cpu().numpy(), g2.cpu().numpy()) if DO_ZG else (np.ones(m), np.ones(m)); t3 = time.perf_counter()
-    z[0] = z[0] + 1e-6 * np.sign(a); z[1] = z[1] + 1e-6 * np.sign(b)
+    dl = float(os.environ.get('TZ_DELTA', '1e-6')); z[0] = z[0] + dl * np.sign(a); z[1] = z[1] + dl * np.sign(b)
     if DO_SET:
         eng.set_inducing(0, z[0]); eng.set_inducing(1, z[1])
     t4 = time.perf_counter()
