@@ -116,6 +116,8 @@ MASK_CASES = [
     (32, 32, "b0", "matern12", np.linspace(0, 1, 9), np.linspace(0, 1, 9), [0.25, 0.2, 1.0, 1.2, 0.01], 0.3),
     (40, 36, "points", "matern32", np.linspace(0, 1, 12), np.linspace(0, 1, 13), [0.3, 0.25, 0.9, 1.2, 0.01], 0.3),
     (24, 20, "points", "rbf", np.linspace(0, 1, 5), np.linspace(0, 1, 6), [0.3, 0.25, 0.9, 1.2, 0.01], 0.0),
+    # M = 45 * 47 = 2115: 17 panels of the blocked Cholesky, the last one ragged, trailing updates in two column strips
+    (96, 90, "b0", "matern12", np.linspace(0, 1, 46), np.linspace(0, 1, 48), [0.3, 0.25, 0.9, 1.2, 0.01], 0.3),
 ]
 
 
