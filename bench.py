@@ -32,6 +32,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -68,6 +69,36 @@ class Adam:
         mh, vh = self.m / (1 - self.b1 ** self.t), self.v / (1 - self.b2 ** self.t)
         self.x = self.x - self.lr * mh / (np.sqrt(vh) + self.eps)
         return self.x
+
+
+class FitLoop5:
+    """The same Adam fit loop on the 5 raw parameters in plain Python floats (theta = softplus(raw), noise + 1e-4; gradient
+    through the softplus): the arithmetic of Adam / theta_from_raw below without numpy's per-call overhead on 5-element arrays
+    (11 us per step, measured -- 4 % of a 0.27 ms step)."""
+
+    def __init__(self, raw, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
+        self.x = [float(r) for r in raw]
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.m, self.v, self.t = [0.0] * 5, [0.0] * 5, 0
+
+    def theta(self):
+        th = [(r if r > 0.0 else 0.0) + math.log1p(math.exp(-abs(r))) for r in self.x]
+        th[4] += 1e-4
+        return th
+
+    def update(self, grad_theta):
+        """One Adam step that MAXIMISES the ELBO, from the gradient w.r.t. theta."""
+        self.t += 1
+        b1, b2 = self.b1, self.b2
+        c1, c2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        x, m, v = self.x, self.m, self.v
+        if hasattr(grad_theta, "tolist"):
+            grad_theta = grad_theta.tolist()          # (numpy scalars are slow operands)
+        for i in range(5):
+            g = -grad_theta[i] / (1.0 + math.exp(-x[i]))          # d softplus / d raw = sigmoid(raw); minimise -ELBO
+            m[i] = b1 * m[i] + (1.0 - b1) * g
+            v[i] = b2 * v[i] + (1.0 - b2) * g * g
+            x[i] -= self.lr * (m[i] / c1) / (math.sqrt(v[i] / c2) + self.eps)
 
 
 def theta_from_raw(raw):
@@ -269,19 +300,17 @@ def main():
         n_obs = float(Wg.sum())
         n_points = n_obs
     yy = float((Yg * Yg * Wg).sum())
-    opt = Adam(raw_start(), lr=0.01)
+    opt = FitLoop5(raw_start(), lr=0.01)
 
     def one_step():
-        raw = opt.x
-        th = theta_from_raw(raw.copy())
+        th = opt.theta()
         if args.masked:
             elbo, g, info = eng.elbo_step_masked(Y, W, n_obs, yy, th)
         elif ext is not None:
             elbo, g, info = ext.step(Y, yy, th)
         else:
             elbo, g, info = eng.elbo_step(Y, yy, th)       # multi-rank context: partials -> all-reduce -> finish inside
-        graw = g / (1.0 + np.exp(-raw))              # softplus chain rule
-        opt.step(-graw)
+        opt.update(g)                                     # softplus chain rule + Adam
         return elbo, info
 
     def barrier():

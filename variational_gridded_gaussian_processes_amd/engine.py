@@ -79,6 +79,7 @@ class Engine:
             check(self.lib.vggp_set_allreduce(self._h, self._cb, None))
         self.m1 = self.m2 = self.n1 = self.n2 = 0
         self.planned = False
+        self._step_bufs = None
         self.plan_token = 0          # bumped by every plan(): a model sharing this engine re-plans when it is not the last planner
 
     @staticmethod
@@ -153,13 +154,14 @@ class Engine:
     def elbo_step(self, Y: torch.Tensor, yy_total: float, theta: Sequence[float]):
         """-> (elbo, grad[5] wrt (ell1, ell2, s1, s2, sigma2), info dict)."""
         self._check_Y(Y)
-        th = (C.c_double * 5)(*[float(t) for t in theta])
-        elbo = C.c_double()
-        grad = (C.c_double * 5)()
-        info = Info()
-        check(self.lib.vggp_elbo_step(self._h, _ptr(Y), float(yy_total), th, C.byref(elbo), grad, C.byref(info),
-                                      _stream(self.device)))
-        return elbo.value, np.array(list(grad)), self._info(info)
+        b = self._step_bufs           # (host argument blocks of the fit loop's call, allocated once: the call is made ~4000 times a second)
+        if b is None:
+            th, elbo, grad, info = (C.c_double * 5)(), C.c_double(), (C.c_double * 5)(), Info()
+            b = self._step_bufs = (th, elbo, grad, info, C.byref(elbo), C.byref(info), np.frombuffer(grad, dtype=np.float64))
+        th = b[0]
+        th[0], th[1], th[2], th[3], th[4] = theta
+        check(self.lib.vggp_elbo_step(self._h, _ptr(Y), float(yy_total), th, b[4], b[2], b[5], _stream(self.device)))
+        return b[1].value, b[6].copy(), self._info(b[3])
 
     def elbo_step_masked(self, Ym: torch.Tensor, W: torch.Tensor, n_obs: float, yy_obs: float, theta: Sequence[float]):
         """Masked grid: Ym = W*Y and W (0/1 float64) are [n2, n1]; -> (elbo, grad[5], info)."""
