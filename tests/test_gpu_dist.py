@@ -403,3 +403,58 @@ def test_zgrad_of_a_row_sharded_job(engine, world):
     for rank, e, gz1, gz2 in res:
         assert abs(e - ref.elbo) <= 1e-9 * abs(ref.elbo)
         assert np.abs(gz1 - r1).max() <= 1e-6 * np.abs(r1).max() and np.abs(gz2 - r2).max() <= 1e-6 * np.abs(r2).max(), rank
+
+
+# ---- RCCL between devices: runs only where more than one GPU is visible ----------------------------------------------------------
+def _rccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import dense as D
+    from variational_gridded_gaussian_processes_amd.sharded import make_engine, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # bootstrap of the unique id only
+    try:
+        X, y, x1, x2 = D.gen_grid(N1, N2)
+        rows = shard_rows(N2, rank, world)
+        dev = f"cuda:{rank}"
+        eng = make_engine(rank, transport="rccl")                      # one device per rank, the context owns the communicator
+        assert eng.n_ranks == world and eng.transport == "rccl"
+        eng.plan("matern32", "points", np.linspace(0, 1, M1), x1, "matern32", "points", np.linspace(0, 1, M2), x2[rows],
+                 n_total=N1 * N2, warm_start=True)
+        Y = torch.tensor(y.reshape(N2, N1)[rows], device=dev)
+        yy = eng.sumsq(Y)
+        out = []
+        for k in range(NSTEP):
+            e, g, info = eng.elbo_step(Y, yy, np.array(THETA) * (1.0 + 0.01 * k))
+            out.append((e, g))
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_rccl_all_reduce_between_two_devices():
+    """The transport bench.py --gpus N uses -- one process per GPU, RCCL communicator inside the context, partials graph ->
+    ncclAllReduce on the step's stream -> finish graph -- on two real devices: every rank equals the oracle on the full grid."""
+    from oracle import dense as D, kron as Kr
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    X, y, x1, x2 = D.gen_grid(N1, N2)
+    f1 = Kr.Factor("points", "matern32", np.linspace(0, 1, M1), x1)
+    f2 = Kr.Factor("points", "matern32", np.linspace(0, 1, M2), x2)
+    for k in range(NSTEP):
+        ref = Kr.elbo_step(y.reshape(N2, N1), f1, f2, np.array(THETA) * (1.0 + 0.01 * k))
+        for rank, out in res:
+            e, g = out[k]
+            assert abs(e - ref.elbo) <= 1e-9 * abs(ref.elbo) and np.abs(g - ref.grad).max() <= 1e-7 * np.abs(ref.grad).max()
+        assert res[0][1][k][0] == res[1][1][k][0]
