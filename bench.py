@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   stages_us         per-launch-group breakdown of one step (HIP events on the launch stream, plain launches)
   cold_ms_per_step  the same loop with the eigensolver's warm start off
   m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
+  posterior_1M_points  vggp_posterior (mean + variance) at 2^20 scattered test points after a headline step
   svgp_train_z      ms per optimiser iteration of an SVGP whose inducing points are trained (step + Z-gradient + in-place move)
   scattered         vggp_elbo_step_scattered: ms per step for 100 000 points that form no grid (B0 cells, m_d = 32)
   masked_md128      masked 2048 x 2048 grid, 30 % missing, m_d = 128 (M = 16384): ms per step of the dense M-space solver
@@ -387,6 +388,7 @@ def main():
             out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=40 if md < 256 else 12,
                                                     warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
             out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
+            out["posterior_1M_points"] = posterior_bench(eng, Y, yy, args.kind, x1, x2, m)
             out["svgp_train_z"] = trainz_bench(eng, Y, yy, x1, x2, m)
             out["scattered"] = scattered_bench(eng)
             out["masked_md128"] = masked_md128_bench(eng, D)
@@ -449,6 +451,24 @@ def slab_bench(eng, D, kind, m, n1=4096, n2=1024):
     return {"ms_per_step": ms, "grid_points_per_s": n1 * n2 / (ms * 1e-3), "project_kernel": eng.project_kernel_name(),
             "project_us": us, "project_flops": fl, "project_TFLOP/s": fl / (us * 1e-6) / 1e12,
             "project_frac_of_fp64_peak": fl / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS}
+
+
+def posterior_bench(eng, Y, yy, kind, x1, x2, m, ns=1 << 20):
+    """Prediction: vggp_posterior (mean + variance, kronecker_structure.py:199-230) at 2^20 scattered test points after a step
+    of the headline workload; the one-off cold re-solve that follows a warm step is outside the timed region."""
+    import torch
+    g = np.linspace(0, 1, m)
+    eng.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=True)
+    eng.elbo_step(Y, yy, THETA0)
+    xs = torch.tensor(np.random.default_rng(0).uniform(0, 1, (ns, 2)), device=eng.device)
+    eng.posterior(xs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        mean, var = eng.posterior(xs)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    return {"points": ns, "ms": dt * 1e3, "points_per_s": ns / dt}
 
 
 def trainz_bench(eng, Y, yy, x1, x2, m, kind="matern32", steps=60, warmup=15):

@@ -1288,25 +1288,33 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m1 = c->desc.m1, m2 = c->desc.m2;
-    const long chunk = std::min<long>(ns, 8192);
+    // chunks of 64 Ki points: 6 launches each; 8 Ki-point chunks left the 1 M-point prediction launch-bound (15.4 ms, 13 TFLOP/s)
+    const long chunk = std::min<long>(ns, 65536);
     if (ns == 0) return VGGP_OK;
-    // per chunk: A(m x c), B(m x c), T(m x c) for both dims, T2sq, U, Uv (m1 x c)
-    const size_t per = (size_t)chunk * (3 * m1 + 4 * m2 + 2 * m1);
+    // per chunk: A(m x c), T(m x c) for both dims, T2sq, U, Uv (m1 x c); once: W_d = Q_d^T L0_d^-1 (m x m)
+    const size_t per = (size_t)chunk * (2 * m1 + 3 * m2 + 2 * m1) + (size_t)(m1 * m1 + m2 * m2);
     int rc = vg_accurate_state(c, st);
     if (rc) return rc;
     if ((rc = vg_ensure_misc(c, per * sizeof(double)))) return rc;
     double* p = (double*)c->misc;
     double* A1 = p; p += m1 * chunk;
-    double* B1 = p; p += m1 * chunk;
     double* T1 = p; p += m1 * chunk;
     double* A2 = p; p += m2 * chunk;
-    double* B2 = p; p += m2 * chunk;
     double* T2 = p; p += m2 * chunk;
     double* T2sq = p; p += m2 * chunk;
     double* U = p; p += m1 * chunk;
     double* Uv = p; p += m1 * chunk;
+    double* W1 = p; p += m1 * m1;
+    double* W2 = p;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, st));   // wq = [beta rs / v | invD - 1]
+    {
+        VgGemmBatch g;                                                              // whitening and rotation in one operand
+        vg_gemm_init(&g);
+        vg_gemm_add(&g, d1.QtPrev, m1, 1, d1.Linv0, m1, 1, W1, (int)m1, (int)m1, (int)m1, (int)m1);
+        vg_gemm_add(&g, d2.QtPrev, m2, 1, d2.Linv0, m2, 1, W2, (int)m2, (int)m2, (int)m2, (int)m2);
+        VG_HIP(vg_gemm_launch(&g, st));
+    }
     for (long off = 0; off < ns; off += chunk) {
         const int cn = (int)std::min<long>(chunk, ns - off);
         VgFactorJob fj[2] = {
@@ -1315,12 +1323,8 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
         VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
         VgGemmBatch g;
         vg_gemm_init(&g);
-        vg_gemm_add(&g, d1.Linv0, m1, 1, A1, cn, 1, B1, cn, (int)m1, cn, (int)m1);
-        vg_gemm_add(&g, d2.Linv0, m2, 1, A2, cn, 1, B2, cn, (int)m2, cn, (int)m2);
-        VG_HIP(vg_gemm_launch(&g, st));
-        vg_gemm_init(&g);
-        vg_gemm_add(&g, d1.QtPrev, m1, 1, B1, cn, 1, T1, cn, (int)m1, cn, (int)m1);
-        vg_gemm_add(&g, d2.QtPrev, m2, 1, B2, cn, 1, T2, cn, (int)m2, cn, (int)m2);
+        vg_gemm_add(&g, W1, m1, 1, A1, cn, 1, T1, cn, (int)m1, cn, (int)m1);
+        vg_gemm_add(&g, W2, m2, 1, A2, cn, 1, T2, cn, (int)m2, cn, (int)m2);
         VG_HIP(vg_gemm_launch(&g, st));
         VG_HIP(vg_scale_sq_launch(T2, T2sq, (long)m2 * cn, st));
         vg_gemm_init(&g);
