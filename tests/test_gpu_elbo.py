@@ -512,9 +512,9 @@ def test_readouts_after_warm_rbf_steps_have_cold_accuracy(engine):
             assert rel(pm.cpu().numpy(), om) < 1e-6 and rel(pv.cpu().numpy(), ov) < 1e-5
 
 
-def _rbf_trajectory(engine, profile, steps=26):
+def _rbf_trajectory(engine, profile, steps=26, m=64):
     """A smooth 1 %-per-step path with one 30 % jump: subspace start, Newton Ritz solve, riders -- and their fall-backs."""
-    n, m = 192, 64
+    n = 192
     X, y, x1, x2 = D.gen_grid(n, n)
     g = np.linspace(0, 1, m)
     engine.plan("rbf", "points", g, x1, "rbf", "points", g, x2, warm_start=True)
@@ -544,6 +544,22 @@ def test_rbf_warm_chain_with_jump_vs_oracle(engine):
         assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, info)
         assert rel(grad, ref.grad) < RTOL, (k, info)
     assert all(o[3]["status"] == 0 for o in out)
+
+
+@pytest.mark.parametrize("m", [24, 32, 40, 48])
+def test_rbf_warm_chain_at_small_inducing_counts(engine, m):
+    """m_d <= 48, where the Gram matrices are not rank-deficient by the 3 rank <= m rule but still carry the near-null cluster:
+    the relaxed subspace start (Ritz problem of rank + 2 rows, at least 8 rows left to sweep) along the same path with a jump,
+    against the oracle; and it must actually be taken (no Jacobi rounds on the smooth stretch)."""
+    out, (Yn, f1, f2) = _rbf_trajectory(engine, profile=False, m=m)
+    for k in (0, 1, 2, 5, 9, 14, 15, 16, 17, 25):
+        th, elbo, grad, info = out[k]
+        ref = Kr.elbo_step(Yn, f1, f2, th)
+        assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, info)
+        assert rel(grad, ref.grad) < RTOL, (k, info)
+    assert all(o[3]["status"] == 0 for o in out)
+    if m >= 32:
+        assert any(sum(o[3]["rounds"]) == 0 for o in out[6:15]), [o[3]["rounds"] for o in out[6:15]]
 
 
 def test_riders_and_graph_equal_plain_launches(engine):

@@ -1006,10 +1006,18 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
             VgDim& d = c->d[k];
             const int rank = (c->h_out->counters[k][1] >> 8) & 0x1ff;
             int want = 0;
+            static const bool relax = getenv("VGGP_NO_SUB_RELAX") == nullptr;
             if (d.Zs && rank >= 1 && 3 * rank <= d.m) {
                 want = ((rank + 4 + 7) / 8) * 8;
                 if (want < 16) want = 16;
                 if (want > 64 || 2 * want > d.m) want = 0;
+            } else if (relax && d.Zs && rank >= 1 && d.m <= 64 && rank + 2 <= d.m - 8) {
+                // small inducing counts (m_d = 32: numerical rank ~22): not "rank-deficient" by the rule above, but the near-null
+                // cluster is what costs the warm Jacobi its 3-5 sweeps -- deflating the range part still pays as long as the Ritz
+                // problem fits the Newton start (<= 48) and some rows are left over (195 -> 171 us at m_d = 32, 253 -> 203 at 48)
+                want = ((rank + 2 + 3) / 4) * 4;
+                if (want > d.m - 8) want = d.m - 8;
+                if (want < 8 || want > 48) want = 0;
             }
             if (want == 0) d.sub_r = 0;
             else if (want > d.sub_r || want < d.sub_r - 8) d.sub_r = want;
