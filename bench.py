@@ -8,6 +8,14 @@ iteration of the notebooks' fit loop (5_gridded_kronecker_structure_models.ipynb
 hyper-parameters therefore change every step (the eigensolver's warm start is real work, not a
 cached answer).  Observations are resident in HBM before the timed region.
 
+`python3 bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks ITSELF: before this process imports
+torch or touches the GPU it spawns `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py <same arguments>` as a child, relays its one JSON line and exits with its code (the driver's own torchrun command
+works unchanged: with WORLD_SIZE in the environment this process is a rank).  A --gpus / WORLD_SIZE mismatch is an error
+(exit 2).  The collective is the library's RCCL communicator wherever the node has >= N devices; with fewer devices the ranks
+share GPUs through the host-callback transport over gloo and the line says so ("rehearsal": true -- never a reported number).
+`--strong` = BASELINE configs[3]'s shape: a fixed n1 x n2 grid (default 4096 x 4096) whose rows are split N ways.
+
 N > 1 (weak scaling): every rank owns an (n2_local x n1) slab of an (n2_local*N) x n1 grid (rows of Y = dimension 2); the
 step of the multi-rank context is  partials -> ONE all-reduce of the packed payload {G2,H2,C,C1,C2} (RCCL communicator
 owned by the library, csrc/comm.hip) -> finish.  BASELINE configs[3] is `--gpus 4 --n1 4096 --n2-local 1024`;
@@ -206,6 +214,50 @@ def pmc_traffic(n1, n2_loc, m):
     return d, "profiles/r2_pmc_traffic.json"
 
 
+def _visible_devices():
+    """Number of GPUs WITHOUT initialising HIP in this process (it may still have to spawn the ranks): the KFD topology lists
+    one node per agent, GPUs are the ones with SIMDs; ROCR/HIP_VISIBLE_DEVICES narrow it."""
+    n = 0
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except OSError:
+                continue
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""])) if n else len([t for t in v.split(",") if t.strip()])
+    return n
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: this process has not imported torch nor touched the GPU; it becomes the supervisor of
+    N fresh rank processes (torch.distributed.run spawns them; nothing is exec'ed from a GPU-initialised process)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["VGGP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,9 +273,22 @@ def main():
     ap.add_argument("--cold", action="store_true", help="disable the eigensolver warm start")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip cold_ms_per_step / m_d_sweep / kron_solve / factor_build")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL communicator owned by the library, the measured path) | "
-                                                      "gloo (rehearsal of N>1 ranks sharing one GPU; never a reported number)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling on BASELINE configs[3]'s grid: a fixed n1 x n2 grid "
+                                                          "(default 4096 x 4096; --n1 / --n2 change it) whose rows are split over the ranks")
+    ap.add_argument("--n2", type=int, default=None, help="global number of grid rows of the --strong grid")
+    ap.add_argument("--backend", default="auto", help="auto (RCCL communicator owned by the library when the node has >= N GPUs, "
+                                                      "the measured path; otherwise the gloo rehearsal) | nccl | gloo (N > 1 ranks "
+                                                      "sharing GPUs through the host-callback transport; never a reported number)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))            # (before torch is imported: this process never touches the GPU)
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; they must agree",
+              file=sys.stderr)
+        sys.exit(2)
 
     # stdout carries exactly ONE line, the JSON: native libraries (gloo's "[Gloo] Rank 0 is connected ..." banner, RCCL
     # notices) print to file descriptor 1, so everything else is sent to stderr for the whole run
@@ -239,21 +304,36 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from variational_gridded_gaussian_processes_amd import Engine
     from variational_gridded_gaussian_processes_amd.sharded import ExternalCollectiveStep, make_engine
-    from oracle import dense as D      # synthetic-data generator only (gen_2d layout + the notebooks' latent function)
+    from variational_gridded_gaussian_processes_amd import datagen as D      # gen_2d layout + the notebooks' latent function
 
     collective = "none"
     ext = None
+    rehearsal = False
+    ndev = torch.cuda.device_count()            # (does not initialise HIP on this stack)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # torch.distributed only bootstraps (unique id, barriers, the max over ranks of the wall time): gloo on the CPU.  The
         # data path is the library's own RCCL communicator.
         dist.init_process_group("gloo")
-        dev = local_rank % max(torch.cuda.device_count(), 1)
+        backend = args.backend
+        if backend == "auto":
+            backend = "nccl" if ndev >= world else "gloo"
+            if backend == "gloo" and rank == 0:
+                print(f"bench.py: {world} ranks on {ndev} GPU(s): RCCL refuses duplicate devices, so the ranks share GPUs through "
+                      f"the host-callback transport over gloo -- a REHEARSAL of the multi-rank sequence, not a measurement",
+                      file=sys.stderr)
+        if backend == "nccl" and ndev < world:
+            if rank == 0:
+                print(f"bench.py: --backend nccl needs one GPU per rank ({world} ranks, {ndev} GPU(s))", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(2)
+        dev = local_rank % max(ndev, 1)
         torch.cuda.set_device(dev)
-        if args.backend == "gloo":
+        if backend == "gloo":
             eng = make_engine(dev, transport="gloo")
-            collective = "host callback over gloo (rehearsal)"
+            collective = "host callback over gloo (rehearsal: ranks share GPUs)"
+            rehearsal = True
         else:
             ok, eng = 1, None
             try:
@@ -274,22 +354,35 @@ def main():
     else:
         torch.cuda.set_device(0)
         eng = Engine(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    comm = eng.comm_info()                      # what the context itself says: communicator size + transport
+    if ext is None and comm["n_ranks"] != world:
+        print(f"bench.py: the context reports a communicator of {comm['n_ranks']} rank(s), the job has {world}", file=sys.stderr)
+        sys.exit(3)
 
-    n1 = args.n1 if args.n1 is not None else args.n
-    n2_loc = args.n2_local if args.n2_local is not None else args.n
     m = args.m
-    n2_glob = n2_loc * world
-    # global grid: x1 in [0,1] (n1 points), x2 in [0, world] (n2_loc*world points, same spacing per slab)
-    X, y, x1, x2 = D.gen_grid(n1, n2_glob, lims2=(0.0, float(world)), seed=0)
+    if args.strong:
+        # BASELINE configs[3]: ONE fixed grid on [0,1]^2 whose rows (dimension 2) are split over the ranks
+        n1 = args.n1 if args.n1 is not None else 4096
+        n2_glob = args.n2 if args.n2 is not None else 4096
+        if n2_glob % world:
+            print(f"bench.py: --strong needs the {n2_glob} grid rows to divide over {world} ranks", file=sys.stderr)
+            sys.exit(2)
+        n2_loc = n2_glob // world
+        x2_hi = 1.0
+    else:
+        n1 = args.n1 if args.n1 is not None else args.n
+        n2_loc = args.n2_local if args.n2_local is not None else args.n
+        n2_glob = n2_loc * world
+        x2_hi = float(world)
+    # weak: global grid x1 in [0,1] (n1 points), x2 in [0, world] (n2_loc*world points, same spacing per slab)
+    X, y, x1, x2 = D.gen_grid(n1, n2_glob, lims2=(0.0, x2_hi), seed=0)
     del X
     Yg = y.reshape(n2_glob, n1)
     sl = slice(rank * n2_loc, (rank + 1) * n2_loc)
     basis = "b0" if args.masked else "points"
     kind = "matern12" if args.masked else args.kind
     g1 = np.linspace(0, 1, m + 1 if args.masked else m)
-    g2 = np.linspace(0, float(world), m + 1 if args.masked else m)
+    g2 = np.linspace(0, x2_hi, m + 1 if args.masked else m)
     eng.plan(kind, basis, g1, x1, kind, basis, g2, x2[sl], n_total=n1 * n2_glob, warm_start=not args.cold)
     Y = torch.tensor(Yg[sl], device=eng.device)
     n_points = n1 * n2_glob
@@ -301,6 +394,7 @@ def main():
         n_obs = float(Wg.sum())
         n_points = n_obs
     yy = float((Yg * Yg * Wg).sum())
+    del y, Yg
     opt = FitLoop5(raw_start(), lr=0.01)
 
     def one_step():
@@ -350,12 +444,16 @@ def main():
             "metric": "ELBO-step grid-points/sec (value + 5-component gradient), 1024x1024 RBF grid per GPU",
             "value": n_points / (ms_per_step * 1e-3), "unit": "grid-points/s" if not args.masked else "observed grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"2D Kronecker {kind} GP ({'B0 cells, 30 % of the grid masked out' if args.masked else 'points basis'}), "
                                     f"{n2_glob}x{n1} grid ({n2_loc}x{n1} per GPU), m_d={m}, Adam fit loop (lr 0.01), "
                                     f"eigensolver warm start {'off' if args.cold else 'on'}"),
-                       "parallelism": (f"grid rows sharded over {world} rank(s), one all-reduce of {eng.payload_len} doubles per "
-                                       f"step: {collective}") if world > 1 else "single GPU"},
+                       "parallelism": (f"grid rows sharded over {world} rank(s) on {min(ndev, world)} GPU(s), one all-reduce of "
+                                       f"{eng.payload_len} doubles per step: {collective}; the context reports a communicator "
+                                       f"of {comm['n_ranks']} rank(s), transport {comm['transport']}") if world > 1 else "single GPU",
+                       "comm": {"n_ranks": comm["n_ranks"], "transport": comm["transport"], "devices_visible": ndev,
+                                "self_launched": os.environ.get("VGGP_BENCH_SELF_LAUNCHED") == "1"}},
+            "rehearsal": rehearsal,
             "elbo_last": elbo,
             "jacobi": {"sweeps": info["sweeps"], "rounds": info["rounds"], "jitter": info["jitter"], "polished": info.get("polished")},
             "stages_us": stages_us,
@@ -612,12 +710,11 @@ def kron_solve_bench(eng, n, reps=20):
     diagonal-block inverses, block-doubling inverse, four triangular-aware GEMMs -- is inside the timed region).  Algorithmic
     bytes and flops as SURVEY.md section 8d defines them: 16 n1 n2 + 4 (n1^2 + n2^2) bytes, 2 n1^2 n2 + 2 n2^2 n1 flops."""
     import torch
-    from oracle import kron as Kr
-    z = np.linspace(0, 1, n)
-    K1, _ = Kr.points_factor("matern12", z, z, 0.2)
-    K2, _ = Kr.points_factor("matern32", z, z, 0.05)
-    L1, _, _ = eng.cholesky_inverse(torch.tensor(K1, device=eng.device))
-    L2, _, _ = eng.cholesky_inverse(torch.tensor(K2, device=eng.device))
+    z = torch.linspace(0, 1, n, dtype=torch.float64, device=eng.device)
+    K1 = eng.factor_build("matern12", "points", z, z, 0.2)[2]
+    K2 = eng.factor_build("matern32", "points", z, z, 0.05)[2]
+    L1, _, _ = eng.cholesky_inverse(K1)
+    L2, _, _ = eng.cholesky_inverse(K2)
     Yk = torch.randn(n, n, dtype=torch.float64, device=eng.device)
     for _ in range(3):
         eng.kron_solve(L1, L2, Yk)
@@ -627,7 +724,7 @@ def kron_solve_bench(eng, n, reps=20):
         Xk = eng.kron_solve(L1, L2, Yk)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    resid = float((torch.tensor(K1, device=eng.device) @ Xk @ torch.tensor(K2, device=eng.device).T - Yk).abs().max())
+    resid = float((K1 @ Xk @ K2.T - Yk).abs().max())
     alg_bytes = 16 * n * n + 4 * (n * n + n * n)
     flops = 4 * n ** 3
     return {"n": n, "ms": dt * 1e3, "GB/s": alg_bytes / dt / 1e9, "algorithmic_bytes": alg_bytes,

@@ -29,6 +29,18 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert getattr(lib, name) is not None
 
 
+def test_library_exports_nothing_beyond_the_header(lib):
+    """The dynamic symbol table of the shipped .so holds exactly the declared vggp_* entry points (no debug back doors)."""
+    import subprocess
+    from variational_gridded_gaussian_processes_amd import _lib
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(nm):
+        nm = "nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("vggp_")}
+    assert exported == set(_lib.SYMBOLS), exported ^ set(_lib.SYMBOLS)
+
+
 def test_struct_layouts_match_header():
     from variational_gridded_gaussian_processes_amd._lib import Desc, Info
     assert C.sizeof(Desc) == 4 * 4 + 5 * 8 + 4 * 8 + 2 * 4

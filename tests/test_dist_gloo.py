@@ -1,7 +1,11 @@
-"""CPU test of the N > 1 protocol with gloo, world_size 2: every rank computes the packed payload of its row
-shard, ONE all-reduce sums it, every rank finishes redundantly -- and equals the single-rank result.
-(The per-rank arithmetic here is the oracle's; on the GPU box the same seam is vggp_elbo_partials ->
-torch.distributed.all_reduce -> vggp_elbo_finish, see bench.py.)"""
+"""CPU test of the N > 1 PROTOCOL ONLY (gloo, world_size 2): every rank computes the packed payload of its row shard, ONE
+all-reduce sums it, every rank finishes redundantly -- and equals the single-rank result.  The per-rank arithmetic here is
+the ORACLE's (there is no GPU in the CPU suite, and the product has no CPU path): this proves that the payload
+{G2, H2, C, C1, C2} + y^T y is sufficient and that its sum over row shards is exact, nothing about the HIP partials / finish.
+The product's own multi-rank step (vggp_elbo_step on an n_ranks > 1 context: partials graph -> the context's all-reduce ->
+finish graph) is tested on the GPU in tests/test_gpu_dist.py: 2 / 3 / 4 ranks sharing one GPU through the host-callback
+transport over gloo, the failure path of a rank, an RCCL communicator of size one, and RCCL between two devices wherever two
+are visible."""
 import os
 import sys
 

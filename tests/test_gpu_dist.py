@@ -405,6 +405,73 @@ def test_zgrad_of_a_row_sharded_job(engine, world):
         assert np.abs(gz1 - r1).max() <= 1e-6 * np.abs(r1).max() and np.abs(gz2 - r2).max() <= 1e-6 * np.abs(r2).max(), rank
 
 
+# ---- failure of one rank: every rank gets an error, nobody hangs -----------------------------------------------------------------
+FAULT_STEP = 3          # (the step counter of a context starts at 1)
+
+
+def _fault_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    if rank == 1:
+        os.environ["VGGP_FAULT_PARTIALS_AT"] = str(FAULT_STEP)      # this rank's partials "fail" at its 3rd step (csrc/api.hip)
+    import torch.distributed as dist
+    from oracle import dense as D
+    from variational_gridded_gaussian_processes_amd import VggpError
+    from variational_gridded_gaussian_processes_amd.sharded import make_engine, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, x1, x2 = D.gen_grid(N1, N2)
+        rows = shard_rows(N2, rank, world)
+        eng = make_engine(0, transport="gloo")
+        eng.plan("matern32", "points", np.linspace(0, 1, M1), x1, "matern32", "points", np.linspace(0, 1, M2), x2[rows],
+                 n_total=N1 * N2, warm_start=True)
+        Y = torch.tensor(y.reshape(N2, N1)[rows], device="cuda:0")
+        yy = eng.sumsq(Y)
+        out = []
+        for k in range(5):
+            th = np.array(THETA) * (1.0 + 0.01 * k)
+            try:
+                e, g, info = eng.elbo_step(Y, yy, th)
+                out.append(("ok", e))
+            except VggpError as ex:
+                out.append(("err", ex.code, str(ex)))
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_is_an_error_on_every_rank_not_a_hang(engine):
+    """a rank whose half of the step fails must not leave its peers inside the all-reduce.  Rank 1's partials fail at
+    step 3 (fault injection): it still joins the collective, with a zero payload and the failure word set, so BOTH ranks return
+    an error for that step (the failing rank its own, the peer VGGP_ERCCL) and both continue with the next step, which again
+    equals the single-rank result."""
+    from oracle import dense as D
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    X, y, x1, x2 = D.gen_grid(N1, N2)
+    engine.plan("matern32", "points", np.linspace(0, 1, M1), x1, "matern32", "points", np.linspace(0, 1, M2), x2, warm_start=True)
+    Y = torch.tensor(y.reshape(N2, N1), device="cuda")
+    for k in range(5):
+        e1, _, _ = engine.elbo_step(Y, engine.sumsq(Y), np.array(THETA) * (1.0 + 0.01 * k))
+        for rank, out in res:
+            if k == FAULT_STEP - 1:
+                assert out[k][0] == "err", (rank, out[k])
+                assert out[k][1] == (-3 if rank == 1 else -7), (rank, out[k])          # VGGP_EHIP (injected) / VGGP_ERCCL (peer)
+                assert ("injected fault" in out[k][2]) if rank == 1 else ("rank(s) of the job failed" in out[k][2])
+            else:
+                assert out[k][0] == "ok" and abs(out[k][1] - e1) <= 1e-9 * abs(e1), (rank, k, out[k], e1)
+
+
 # ---- RCCL between devices: runs only where more than one GPU is visible ----------------------------------------------------------
 def _rccl_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)

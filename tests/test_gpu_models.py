@@ -171,6 +171,54 @@ def test_masked_grid_model_matches_dense_oracle(engine):
     assert hist[-1] < hist[0]
 
 
+def test_config5_track_shaped_mask_through_the_model_class(engine):
+    """SURVEY.md section 8d's "track-shaped" variant of BASELINE configs[4]: a 2048 x 2048 lat / lon grid observed only along
+    crossing satellite tracks (datagen.generate_track, the array-level twin of dataloaders.py:290-377: gradient 2, one track every
+    0.1 degrees of a 10-degree box -> ~9.5 % of the grid), handed to Matern12GriddedGP as the observed subset X, y exactly as
+    the reference's notebooks 6 / 61 do.  ELBO, raw-parameter gradients and q(v) against the structured masked oracle on the
+    same (grid, mask); a small case of the same construction against the literal dense restatement."""
+    from variational_gridded_gaussian_processes_amd import datagen as G
+    from variational_gridded_gaussian_processes_amd.models import Matern12GriddedGP
+    n, nk = 2048, 33
+    X, y, x1, x2 = D.gen_grid(n, n)
+    Wn = G.track_mask(n, n, trajectory_gradient=2, track_sparsity=0.1)
+    assert 0.08 < Wn.mean() < 0.11
+    obs = np.flatnonzero(Wn.reshape(-1) > 0)
+    model = Matern12GriddedGP(torch.tensor(X[obs]), torch.tensor(y[obs]), nk, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    assert model._masked and not model._scattered
+    e = model._elbo()
+    e.backward()
+    mesh = torch.linspace(0, 1, nk).double().numpy()                    # the reference's float32-born mesh values
+    # every row and column of the grid carries a track point here, so the model's grid of unique coordinates is the full one
+    assert len(model._x1) == n and len(model._x2) == n
+    f1, f2 = Kr.Factor("b0", "matern12", mesh, x1, True), Kr.Factor("b0", "matern12", mesh, x2, True)
+    raw = np.zeros(5)
+    ref = Kr.elbo_step_masked(y.reshape(n, n), Wn, f1, f2, Kr.theta_from_raw(raw))
+    g_raw = Kr.grad_raw(ref.grad, raw)
+    got = np.array([model.kernel_1.base_kernel.raw_lengthscale.grad.item(),
+                    model.kernel_2.base_kernel.raw_lengthscale.grad.item(),
+                    model.kernel_1.raw_outputscale.grad.item(), model.kernel_2.raw_outputscale.grad.item(),
+                    model.likelihood.raw_noise.grad.item()])
+    assert abs(e.item() - ref.elbo) <= 1e-8 * abs(ref.elbo)
+    assert rel(got, g_raw) < 1e-6
+    qv = model.q_v()
+    rm, rv = Kr.q_v_masked(ref)
+    assert rel(qv.mean.numpy(), rm.reshape(-1)) < 1e-6 and rel(qv.variance.numpy(), rv.reshape(-1)) < 1e-6
+    # the same construction at a size the literal dense restatement can run
+    n, nk = 48, 7
+    X, y, x1, x2 = D.gen_grid(n, n)
+    Wn = G.track_mask(n, n, trajectory_gradient=2, track_sparsity=2.0)
+    obs = np.flatnonzero(Wn.reshape(-1) > 0)
+    model = Matern12GriddedGP(torch.tensor(X[obs]), torch.tensor(y[obs]), nk, (0, 1), (0, 1), engine=engine).to(torch.float64)
+    dm = D.DenseKron(X[obs], y[obs], "b0", "matern12", torch.linspace(0, 1, nk), torch.linspace(0, 1, nk))
+    ed, gd = dm.elbo_and_grad()
+    e = model._elbo()
+    e.backward()
+    assert abs(e.item() - ed.item()) <= 1e-6 * abs(ed.item())
+    qv, qd = model.q_v(), dm.q_v()
+    assert rel(qv.mean.numpy(), qd.mean.detach().numpy()) < 1e-5 and rel(qv.variance.numpy(), qd.variance.detach().numpy()) < 1e-5
+
+
 def test_dense_debug_views_and_prior(engine):
     """_Kuu / _Kuf / _sigma / prior (kept for small sizes) equal the dense restatement."""
     from variational_gridded_gaussian_processes_amd.models import Matern12GriddedGP

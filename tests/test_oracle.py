@@ -300,3 +300,46 @@ def test_scattered_oracle_equals_dense_restatement(basis, kind, g1, g2):
     graw = Kr.grad_raw(st.grad, D.raw_from_constrained(th).numpy())
     assert abs(st.elbo - ed.item()) <= 1e-11 * abs(ed.item())
     assert np.abs(graw - gd_raw.numpy()).max() <= 1e-10 * np.abs(gd_raw.numpy()).max()
+
+
+# ---- a15: the six third-party primitives the oracle RESTATES, checked against independent torch / scipy implementations --------
+# (gpytorch / linear_operator are not importable here, so parity at that boundary stays "unpinned"; but gpytorch's classes wrap
+# torch.distributions.MultivariateNormal, torch.nn.functional.softplus and dense Cholesky solves, all of which ARE importable.)
+def test_restated_primitives_against_torch_and_scipy():
+    import scipy.linalg
+    import scipy.special
+    rng = np.random.default_rng(7)
+    n = 40
+    A = rng.standard_normal((n, n))
+    cov = torch.tensor(A @ A.T / n + 0.3 * np.eye(n))
+    y = torch.tensor(rng.standard_normal(n))
+    # MultivariateNormal(0, C).log_prob(y)  (kronecker_structure.py:273)
+    ref = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), covariance_matrix=cov).log_prob(y)
+    assert abs(float(D.mvn_log_prob(cov, y)) - float(ref)) <= 1e-12 * abs(float(ref))
+    # lazify(A).inv_matmul(B) = A^-1 B  (:269)
+    B = torch.tensor(rng.standard_normal((n, 7)))
+    assert torch.allclose(D.inv_matmul(cov, B), torch.linalg.solve(cov, B), rtol=1e-11, atol=1e-13)
+    assert torch.allclose(D.inv_matmul(cov, y), torch.linalg.solve(cov, y), rtol=1e-11, atol=1e-13)
+    # softplus / inverse, and gpytorch's constraints: Positive() = softplus, GreaterThan(1e-4) = softplus + 1e-4  (:263)
+    x = torch.tensor(rng.uniform(-30, 30, 50))
+    assert torch.allclose(D.softplus(x), torch.nn.functional.softplus(x), rtol=1e-14, atol=0)
+    assert torch.allclose(D.inv_softplus(D.softplus(x[x > -20])), x[x > -20], rtol=1e-9, atol=1e-9)
+    raw = torch.tensor(rng.uniform(-3, 3, 5))
+    th = D.constrained_from_raw(raw)
+    assert torch.allclose(th[:4], torch.nn.functional.softplus(raw[:4])) and abs(float(th[4] - torch.nn.functional.softplus(raw[4])) - 1e-4) < 1e-15
+    assert torch.allclose(D.raw_from_constrained(th.tolist()), raw, rtol=1e-9, atol=1e-9)
+    # ToeplitzLinearOperator(first_row).to_dense()[i, j] = r[|i - j|]  (:737) -- the B0 Kuu builder against scipy's toeplitz
+    m, delta, ell, s = 9, 0.125, 0.37, 1.3
+    K = D.b0_Kuu_along_dim(m, torch.tensor(delta), torch.tensor(ell), torch.tensor(s)).numpy()
+    assert np.allclose(K, scipy.linalg.toeplitz(K[0]), rtol=0, atol=0) and np.allclose(K, K.T)
+    # Matern / RBF kernels against their Bessel-function definition  k_nu(r) = 2^(1-nu)/Gamma(nu) (sqrt(2 nu) r)^nu K_nu(sqrt(2 nu) r)
+    r = np.linspace(1e-3, 6.0, 60)
+    for kind, nu in (("matern12", 0.5), ("matern32", 1.5), ("matern52", 2.5)):
+        z = np.sqrt(2 * nu) * r
+        bessel = 2.0 ** (1 - nu) / scipy.special.gamma(nu) * z ** nu * scipy.special.kv(nu, z)
+        assert np.allclose(D.kappa(kind, torch.tensor(r)).numpy(), bessel, rtol=1e-10, atol=1e-14), kind
+    assert np.allclose(D.kappa("rbf", torch.tensor(r)).numpy(), np.exp(-0.5 * r * r), rtol=1e-14)
+    # psd_safe_cholesky: no jitter on a PD matrix, the 1e-8 .. 1e-6 ladder on a singular one
+    assert D.psd_safe_cholesky(cov)[1] == 0.0
+    sing = torch.ones(6, 6, dtype=torch.float64)
+    assert D.psd_safe_cholesky(sing)[1] in (1e-8, 1e-7, 1e-6)

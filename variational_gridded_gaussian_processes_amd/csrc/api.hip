@@ -223,7 +223,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.Mk = b.take<double>(m * m);
     }
     c->payload_len = 2 * m2 * m2 + 3 * m1 * m2;
-    c->payload = b.take<double>(c->payload_len);
+    c->payload = b.take<double>(c->payload_len + 8);      // + the peer-failure word of a multi-rank step (payload[payload_len])
     // ---- factor stage
     for (int k = 0; k < 2; ++k) {
         VgDim& d = c->d[k];
@@ -449,6 +449,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         clr.ptr[clr.n] = d.status; clr.nwords[clr.n++] = 2;
         clr.ptr[clr.n] = reinterpret_cast<int*>(d.chol_scratch); clr.nwords[clr.n++] = 16;     // jitter-level flags
         clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 8;                                  // Jacobi progress words (counters, counters2)
+        if (k == 0) { clr.ptr[clr.n] = reinterpret_cast<int*>(c->payload + c->payload_len); clr.nwords[clr.n++] = 2; }   // peer-failure word
         cj[k] = VgCholJob{d.K0, d.L0, dinv_path ? nullptr : d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
         cj[k].Dinv_out = d.Dinv0;
     }
@@ -860,6 +861,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     ms.r2 = c->r2; ms.r2l = c->r2l; ms.dotp = c->dotpart; ms.ol = c->ol;
     ms.m1 = (int)m1; ms.m2 = (int)m2; ms.n_total = (double)c->desc.n_total; ms.yy = yy_total;
     ms.ticket = c->ticket; ms.hout = c->d_hout;
+    // multi-rank step: the word behind the payload travelled through the all-reduce; non-zero = some rank failed its partials
+    ms.peer_fail = (payload == c->payload && (c->n_ranks > 1 || c->comm || c->cb)) ? c->payload + c->payload_len : nullptr;
     for (int k = 0; k < 2; ++k) { ms.jit[k] = c->d[k].jitter; ms.status[k] = c->d[k].status; ms.counters[k] = c->d[k].counters; }
     VG_HIP(vg_dstage_launch(&ms, st));
     VG_MARK(16);
@@ -965,7 +968,15 @@ static int set_theta(vggp_ctx* c, const double theta[5]) {
 
 // host side of the end of a step: the only synchronisation, then unpack the pinned block
 static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vggp_info* info, hipStream_t st) {
-    VG_HIP(hipStreamSynchronize(st));
+    {
+        const int wrc = vg_comm_wait(c, st);          // (plain hipStreamSynchronize unless the context owns an RCCL communicator)
+        if (wrc) {
+            c->warm_run = 0;
+            for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+            c->have_step = false;
+            return wrc;
+        }
+    }
     c->pred_consumed = false;              // the tail of this step left a fresh prediction in Ep / Fp / Wp
     c->acc_valid = false;
     if (c->prof && c->nev > 1) {
@@ -983,6 +994,14 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
         c->have_step = false;
         return VGGP_ESTATE;
+    }
+    if (c->h_out->out[6] != 0.0) {          // the peer-failure word of the all-reduced payload: the sums miss a rank's contribution
+        vg_set_error("rank %d / %d: %.0f rank(s) of the job failed their half of this step; the result is discarded", c->rank,
+                     c->n_ranks, c->h_out->out[6]);
+        c->warm_run = 0;
+        for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+        c->have_step = false;
+        return VGGP_ERCCL;
     }
     *elbo_out = c->h_out->out[0];
     for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
@@ -1143,10 +1162,32 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         const VgGraphKey kp{Y, c->payload, 0.0}, kf{nullptr, c->payload, yy_total};
         rc = run_graph(c, extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, kp, st,
                        [&] { return vg_partials_enqueue(c, Y, c->payload, st, true, extrap, false, apply_ns); }, extrap && !apply_ns);
-        if (rc) return rc;
+        {
+            // fault injection for the failure-path test (tests/test_gpu_dist.py): VGGP_FAULT_PARTIALS_AT=<step number>
+            static const long fault_at = [] { const char* e = getenv("VGGP_FAULT_PARTIALS_AT"); return e ? atol(e) : -1L; }();
+            if (!rc && fault_at >= 0 && c->seq == fault_at) { vg_set_error("injected fault in the partials of step %ld", c->seq); rc = VGGP_EHIP; }
+        }
+        if (rc) {
+            // This rank cannot contribute, but its peers are about to enter the all-reduce: join it with a zero payload and the
+            // failure word set, so that every rank leaves the collective and returns an error instead of hanging in it.
+            char msg[512];
+            snprintf(msg, sizeof(msg), "%s", vggp_last_error());
+            static const double one = 1.0;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t gdrop = nullptr; (void)hipStreamEndCapture(st, &gdrop); if (gdrop) (void)hipGraphDestroy(gdrop); }
+            (void)hipMemsetAsync(c->payload, 0, sizeof(double) * c->payload_len, st);
+            (void)hipMemcpyAsync(c->payload + c->payload_len, &one, sizeof(double), hipMemcpyHostToDevice, st);
+            if (vg_allreduce(c, c->payload, c->payload_len + 1, st) == VGGP_OK) (void)vg_comm_wait(c, st);
+            else vg_comm_abort(c);
+            c->warm_run = 0;
+            for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+            c->have_step = false;
+            vg_set_error("%s", msg);
+            return rc;
+        }
         if (extrap) c->pred_consumed = true;
         c->have_partials = true;
-        if ((rc = vg_allreduce(c, c->payload, c->payload_len, st))) return rc;
+        if ((rc = vg_allreduce(c, c->payload, c->payload_len + 1, st))) return rc;
         rc = run_graph(c, warm ? (subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
                                 : VG_G_FINISH_COLD, kf, st,
                        [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace); });
@@ -1857,10 +1898,13 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
         VG_HIP(hipMemcpyAsync(gz1, gzbuf, sizeof(double) * m1, hipMemcpyDeviceToDevice, st));
         VG_HIP(hipMemcpyAsync(gz2, gzbuf + m1, sizeof(double) * m2, hipMemcpyDeviceToDevice, st));
     }
-    VG_HIP(hipStreamSynchronize(st));
+    { const int wrc_ = vg_comm_wait(c, st); if (wrc_) return wrc_; }
     return VGGP_OK;
 }
 
+// Diagnostic builds only (tools/: -DVGGP_DIAG, or the stamp builds -DVG_EIG_RT / -DVG_CHOL_STAMP): the shipped library exports
+// exactly the symbols include/vggp.h declares (tests/test_cabi.py checks the dynamic symbol table).
+#if defined(VGGP_DIAG) || defined(VG_EIG_RT) || defined(VG_CHOL_STAMP)
 extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
     if (!c || !c->out) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host8, c->out, 8 * sizeof(double), hipMemcpyDeviceToHost));
@@ -1882,6 +1926,7 @@ extern "C" int vggp_debug_read_misc(vggp_ctx* c, void* host, int64_t bytes) {
     VG_HIP(hipMemcpy(host, c->misc, bytes, hipMemcpyDeviceToHost));
     return VGGP_OK;
 }
+#endif
 
 extern "C" const char* vggp_project_kernel_name(void) { return vg_last_project_kernel(); }
 
@@ -1911,6 +1956,6 @@ extern "C" int vggp_sumsq(vggp_ctx* c, const double* y, int64_t n, double* out, 
     const int rca = vg_allreduce(c, c->sumsq_out, 1, st);          // total over the ranks of the context (no-op for one rank)
     if (rca) return rca;
     VG_HIP(hipMemcpyAsync(out, c->sumsq_out, sizeof(double), hipMemcpyDeviceToHost, st));
-    VG_HIP(hipStreamSynchronize(st));
+    { const int wrc_ = vg_comm_wait(c, st); if (wrc_) return wrc_; }
     return VGGP_OK;
 }

@@ -15,7 +15,10 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <sched.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 struct VgRccl {
     void* lib = nullptr;
@@ -23,6 +26,8 @@ struct VgRccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional (present in every RCCL this was built against)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static VgRccl g_rccl;
@@ -39,6 +44,8 @@ static int rccl_load() {
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
+    r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) {
         vg_set_error("librccl.so.1 lacks an expected symbol");
         return VGGP_ERCCL;
@@ -86,6 +93,54 @@ int vg_comm_init(vggp_ctx* c, int n_ranks, int rank, const void* unique_id) {
     return VGGP_OK;
 }
 
+// Give up on the communicator: ncclCommAbort raises the abort flag the collective kernels poll, so an all-reduce that waits
+// for a peer that will never arrive leaves the GPU instead of spinning for ever.  The context stays usable for nothing
+// multi-rank afterwards (every later step returns VGGP_ERCCL).
+void vg_comm_abort(vggp_ctx* c) {
+    if (c->comm) {
+        if (g_rccl.CommAbort) (void)g_rccl.CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
+        else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
+        c->comm = nullptr;
+    }
+    c->comm_dead = true;
+}
+
+// Host side of the end of a multi-rank step: wait for the stream WITHOUT trusting the peers.  A plain hipStreamSynchronize
+// blocks for ever when a peer died before its ncclAllReduce; here the stream is polled together with the communicator's
+// asynchronous error state, and after VGGP_COMM_TIMEOUT_S seconds (default 120) without completion the communicator is
+// aborted and the step returns VGGP_ERCCL.  Single-rank contexts and the callback transport use the plain synchronisation.
+int vg_comm_wait(vggp_ctx* c, hipStream_t st) {
+    if (!c->comm || !g_rccl.CommGetAsyncError) { VG_HIP(hipStreamSynchronize(st)); return VGGP_OK; }
+    static const double limit_s = [] { const char* e = getenv("VGGP_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return VGGP_OK;
+        if (q != hipErrorNotReady) { vg_set_error("hipStreamQuery -> %s", hipGetErrorString(q)); vg_comm_abort(c); return VGGP_EHIP; }
+        if ((spin & 1023) == 1023) {            // every ~1000 polls: the communicator's health and the clock
+            ncclResult_t ae = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(reinterpret_cast<ncclComm_t>(c->comm), &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+                vg_set_error("RCCL reports an asynchronous error on rank %d / %d: %s (communicator aborted)", c->rank, c->n_ranks,
+                             g_rccl.GetErrorString(ae));
+                vg_comm_abort(c);
+                (void)hipStreamSynchronize(st);
+                return VGGP_ERCCL;
+            }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            if (el > limit_s) {
+                vg_set_error("rank %d / %d: the step's all-reduce did not complete within %.0f s (a peer rank is gone?); communicator "
+                             "aborted", c->rank, c->n_ranks, limit_s);
+                vg_comm_abort(c);
+                (void)hipStreamSynchronize(st);
+                return VGGP_ERCCL;
+            }
+            if (el > 0.002) sched_yield();      // a step takes ~0.3 ms: past 2 ms something is slow, stop burning the core
+        }
+    }
+}
+
 void vg_comm_destroy(vggp_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
     c->comm = nullptr;
@@ -111,6 +166,7 @@ int vg_allreduce(vggp_ctx* c, double* buf, long count, hipStream_t st) {
         VG_HIP(hipMemcpyAsync(buf, c->h_stage, sizeof(double) * count, hipMemcpyHostToDevice, st));
         return VGGP_OK;
     }
+    if (c->comm_dead) { vg_set_error("rank %d / %d: the communicator was aborted after an earlier failure", c->rank, c->n_ranks); return VGGP_ERCCL; }
     if (!c->comm) {
         vg_set_error("context of rank %d / %d has no transport: pass the unique id to vggp_create or call vggp_set_allreduce",
                      c->rank, c->n_ranks);
@@ -134,7 +190,7 @@ extern "C" int vggp_allreduce(vggp_ctx* c, double* buf, int64_t count, void* str
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const int rc = vg_allreduce(c, buf, (long)count, st);
     if (rc) return rc;
-    VG_HIP(hipStreamSynchronize(st));
+    { const int wrc_ = vg_comm_wait(c, st); if (wrc_) return wrc_; }      // (polls the communicator: a dead peer is an error, not a hang)
     return VGGP_OK;
 }
 

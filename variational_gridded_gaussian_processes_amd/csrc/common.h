@@ -251,6 +251,7 @@ struct VgMspace {
     // diagnostics straight into the pinned host block (no D2H memcpy nodes in the step graph)
     int* ticket = nullptr;           // device int, zero between launches
     VgHostOut* hout = nullptr;       // device-visible address of the pinned readback block (may be null)
+    const double* peer_fail = nullptr;   // multi-rank step: the failure word behind the all-reduced payload (-> VgHostOut::out[6])
     const double* jit[2] = {nullptr, nullptr};
     const int* status[2] = {nullptr, nullptr};
     const int* counters[2] = {nullptr, nullptr};

@@ -92,6 +92,7 @@ struct vggp_ctx {
     // the context's collective (comm.hip)
     int n_ranks = 1, rank = 0;
     void* comm = nullptr;             // ncclComm_t
+    bool comm_dead = false;           // the communicator was aborted (a peer failed or timed out): multi-rank steps return VGGP_ERCCL
     vggp_allreduce_fn cb = nullptr;   // host-callback transport (rehearsal / other transports)
     void* cb_user = nullptr;
     double* h_stage = nullptr;        // pinned staging of the callback transport
@@ -112,6 +113,8 @@ int vg_ensure_misc(vggp_ctx* c, size_t bytes);
 int vg_comm_init(vggp_ctx* c, int n_ranks, int rank, const void* unique_id);
 void vg_comm_destroy(vggp_ctx* c);
 int vg_allreduce(vggp_ctx* c, double* buf, long count, hipStream_t st);
+void vg_comm_abort(vggp_ctx* c);
+int vg_comm_wait(vggp_ctx* c, hipStream_t st);
 // blocked dense Cholesky + inverse for matrices beyond one workgroup (masked.hip); S is destroyed; status != 0 on failure
 #define VG_DENSE_MB 128
 struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };

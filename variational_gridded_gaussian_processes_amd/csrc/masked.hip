@@ -481,7 +481,7 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
         VG_HIP(hipMemcpyAsync(&c->h_out->status[k], c->d[k].status, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     VG_HIP(hipMemcpyAsync(&c->h_out->counters[1][3], w.cholstatus, sizeof(int), hipMemcpyDeviceToHost, st));
-    VG_HIP(hipStreamSynchronize(st));
+    { const int wrc_ = vg_comm_wait(c, st); if (wrc_) return wrc_; }      // (polls the communicator: a dead peer is an error, not a hang)
     const int hs = c->h_out->counters[1][3];
     *elbo_out = c->h_out->out[0];
     for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
@@ -613,7 +613,7 @@ extern "C" int vggp_elbo_step_scattered(vggp_ctx* c, const double* y, double yy,
         VG_HIP(hipMemcpyAsync(&c->h_out->status[k], c->d[k].status, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     VG_HIP(hipMemcpyAsync(&c->h_out->counters[1][3], w.cholstatus, sizeof(int), hipMemcpyDeviceToHost, st));
-    VG_HIP(hipStreamSynchronize(st));
+    { const int wrc_ = vg_comm_wait(c, st); if (wrc_) return wrc_; }      // (polls the communicator: a dead peer is an error, not a hang)
     const int hs = c->h_out->counters[1][3];
     *elbo_out = c->h_out->out[0];
     for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
@@ -728,7 +728,7 @@ extern "C" int vggp_zgrad_scattered(vggp_ctx* c, const double* y, double* gz1, d
         VG_HIP(hipMemcpyAsync(gz1, gzbuf, sizeof(double) * m1, hipMemcpyDeviceToDevice, st));
         VG_HIP(hipMemcpyAsync(gz2, gzbuf + m1, sizeof(double) * m2, hipMemcpyDeviceToDevice, st));
     }
-    VG_HIP(hipStreamSynchronize(st));
+    { const int wrc_ = vg_comm_wait(c, st); if (wrc_) return wrc_; }      // (polls the communicator: a dead peer is an error, not a hang)
     return VGGP_OK;
 }
 

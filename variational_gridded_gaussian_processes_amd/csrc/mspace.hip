@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void vg_final_kernel(const VgMspace ms) {
         const double o[6] = {elbo, g_l1, g_l2, g_s1, g_s2, g_v};
 #pragma unroll
         for (int q = 0; q < 6; ++q) { ms.out[q] = o[q]; stage[q] = o[q]; }
-        stage[6] = stage[7] = 0.0;
+        stage[6] = ms.peer_fail ? *ms.peer_fail : 0.0;          // ranks that failed their partials (multi-rank step), else 0
+        stage[7] = 0.0;
     }
     // results + diagnostics go to the pinned host block as ONE 128-byte burst: the block is staged in LDS (layout of
     // VgHostOut: out[8], jitter[2], counters[2][4], status[2]) and 16 lanes store one 8-byte word each

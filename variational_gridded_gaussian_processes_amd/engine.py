@@ -95,6 +95,12 @@ class Engine:
         check(self.lib.vggp_comm_info(self._h, None, None, C.byref(t)))
         return {0: "none", 1: "rccl", 2: "callback"}[t.value]
 
+    def comm_info(self) -> dict:
+        """What the CONTEXT reports about its collective (vggp_comm_info): communicator size, this rank, transport."""
+        n, r, t = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.vggp_comm_info(self._h, C.byref(n), C.byref(r), C.byref(t)))
+        return {"n_ranks": n.value, "rank": r.value, "transport": {0: "none", 1: "rccl", 2: "callback"}[t.value]}
+
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
         """The context's sum all-reduce on a contiguous float64 GPU tensor, in place."""
         check(self.lib.vggp_allreduce(self._h, _ptr(t), t.numel(), _stream(self.device)))

@@ -38,6 +38,20 @@ def make_engine(device: Optional[int] = None, group: Optional["dist.ProcessGroup
             t = torch.from_numpy(view)                  # shares the pinned staging buffer of the library
             dist.all_reduce(t, group=group)
         return Engine(device, world, rank, None, allreduce)
+    # Pre-flight: ncclCommInitRank is a rendezvous -- a rank that cannot even create its local context (wrong device, no
+    # memory, library not built) would leave its peers waiting in it for ever.  So every rank first proves it can create (and
+    # drop) a single-rank context on its device, and the ranks agree on the outcome over the bootstrap group before any of
+    # them enters the rendezvous.
+    ok, err = 1, None
+    try:
+        Engine(device).close()
+    except Exception as e:          # noqa: BLE001 -- whatever it is, the peers must hear about it
+        ok, err = 0, e
+    flag = torch.tensor([ok])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        raise RuntimeError(f"rank {rank}: a rank of the job cannot create its local context; no communicator was created"
+                           + (f" (this rank: {err})" if err is not None else ""))
     box = [Engine.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     return Engine(device, world, rank, box[0])
