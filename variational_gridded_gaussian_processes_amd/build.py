@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "factor_build.hip", "chol.hip", "trsm.hip", "eigh.hip", "mspace.hip", "masked.hip", "comm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "factor_build.hip", "chol.hip", "trsm.hip", "eigh.hip", "mspace.hip", "thin.hip", "masked.hip", "comm.hip"]
 HEADERS = ["common.h", "ctx.h", "factor_elem.h", "gemm_body.h", os.path.join("..", "..", "include", "vggp.h")]
 LIB = os.path.join(HERE, "libvggp_hip.so")
 

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -28,6 +29,7 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 #include "factor_elem.h"
 
 static void graphs_clear(vggp_ctx* c);
+static int vg_quiesce(vggp_ctx* c);
 
 static const char* VG_STAGE_NAMES[VGGP_NSTAGE] = {
     "factor_build", "cholesky_inverse", "trsm_BV(L^-1[A|dA|dK])", "extrap_basis(3 small gemms)", "gemm_project(S=[B2;V2]Y)",
@@ -83,6 +85,7 @@ extern "C" int vggp_create(vggp_ctx** out, int device, int n_ranks, int rank, co
     VG_HIP(vg_chol_setup());
     VG_HIP(vg_eigh_setup());
     VG_HIP(vg_trsm_setup());
+    VG_HIP(vg_thin_tail_setup());
     vggp_ctx* c = new (std::nothrow) vggp_ctx();
     if (!c) { vg_set_error("out of host memory"); return VGGP_ENOMEM; }
     c->device = device;
@@ -112,7 +115,8 @@ extern "C" int vggp_destroy(vggp_ctx* c) {
     if (!c) return VGGP_OK;
     VgDeviceGuard guard;
     (void)guard.enter(c->device);
-    for (int i = 0; i < 12; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    (void)vg_quiesce(c);
+    for (int i = 0; i < 16; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
     for (int i = 0; i < VG_MAXEV; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < VG_NFORK; ++i) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
@@ -260,6 +264,8 @@ static void layout(vggp_ctx* c, Bump& b) {
             d.rotlog2 = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
             d.roundlog2 = b.take<int>(d.max_rounds);
             d.Zs = b.take<double>(m * m); d.V1s = b.take<double>(m * m); d.Hs = b.take<double>(m * m); d.Ws = b.take<double>(m * m);
+            d.tMV = b.take<double>(VG_THIN_MAXR * m); d.tHV = b.take<double>(VG_THIN_MAXR * m);
+            d.tAM = b.take<double>(VG_THIN_MAXR * VG_THIN_MAXR); d.tAH = b.take<double>(VG_THIN_MAXR * VG_THIN_MAXR);
         }
     }
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
@@ -270,6 +276,8 @@ static void layout(vggp_ctx* c, Bump& b) {
     const char* cce = getenv("VGGP_CC_TARGET");
     c->cc_split = pick_split(cc_tiles, (int)n1, cce ? atoi(cce) : 64);
     c->CCslab = b.take<double>((size_t)c->cc_split * 3 * m1 * m2);
+    c->tCV = b.take<double>(3 * m1 * VG_THIN_MAXR);
+    c->tAC = b.take<double>(3 * VG_THIN_MAXR * VG_THIN_MAXR + 64);      // (+ 64 words of phase stamps in diagnostic builds)
 }
 
 static int check_dim(int kind, int basis, long n, long m, const char* which) {
@@ -304,11 +312,13 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     VG_REQUIRE(desc->n1 < (1L << 24) && desc->n2 < (1L << 24), "vggp_plan: grid axis too long");
     c->planned = false;
     graphs_clear(c);
+    VG_HIP(hipDeviceSynchronize());
     c->warm_run = 0;
     c->refine_next = false;
     c->sub_next = false; c->sub_mode = false; c->sub_r_cap[0] = c->sub_r_cap[1] = 0;
     c->pred_consumed = false;
     c->acc_valid = false; c->last_warm = false; c->last_slabs = false; c->last_payload = nullptr;
+    c->last_thin = false; c->thin_off = false;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -608,7 +618,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
 static bool vg_sub_ident() { static const bool ex = getenv("VGGP_SUB_EXTRAP") != nullptr; return !ex; }
 
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
-                          bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false) {
+                          bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false, bool thin = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 6 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -632,6 +642,106 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     const double* Hr[2] = {H0[0], H0[1]};      // H for the rotation below: a reduced copy when a warm chain's first launch made one
     int hrn[2] = {ghn[0], ghn[1]};
     VgEigJob ej[2];
+    if (warm && subspace && thin) {
+        // ---- THIN chain (thin.hip): numerically rank-deficient Gram matrices, r = numerical rank + margin <= 32 per dimension.
+        // V = the r leading eigenvectors of the previous step (rows of QtPrev); Z = V G (one step of subspace iteration: G
+        // annihilates every null component); V1 = orth(Z) spans range(G); Rayleigh-Ritz on V1 G V1^T gives the range eigenpairs
+        // (W, theta) -- and that is all the ELBO and its gradient need: every rotated quantity is W (V1 . V1^T) W^T of an
+        // r x r matrix, formed by the tail kernel itself.  No complement basis, no full eigensolve, no m x m rotation.
+        const double* Gr[2] = {G0[0], G0[1]};
+        int grn[2] = {ghn[0], ghn[1]};
+        double* gdst[2] = {d1.GH, c->payload};
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, d.QtPrev, d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.sub_r, d.m, d.m, 1, 0, ghn[k], ghs[k]);            // Z = V G
+            if (from_slabs && ghn[k] > 1) {                  // reduced copies of G and H for the later readers
+                vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                vg_gemm_add(&g, d.Id, d.m, 1, H0[k], d.m, 1, gdst[k] + (long)d.m * d.m, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            }
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(8);
+        for (int k = 0; k < 2; ++k)
+            if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; Hr[k] = gdst[k] + (long)c->d[k].m * c->d[k].m; hrn[k] = 1; }
+        VgRowQrJob qj[2];
+        for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; qj[k] = VgRowQrJob{d.TM, d.V1s, d.sub_r, d.m, nullptr, nullptr, 0}; }
+        VG_HIP(vg_rowqr_launch(qj, 2, st, ride ? &c->ride_proj : nullptr));      // + rider: S = [B2;V2] Y
+        if (ride) ride_stage = 1;
+        VG_MARK(9);
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const int r = d.sub_r;
+            vg_gemm_add(&g, d.V1s, d.m, 1, Gr[k], d.m, 1, d.Zs, d.m, r, d.m, d.m, 1, 0, grn[k], ghs[k]);        // T = V1 G
+            vg_gemm_add(&g, d.V1s, d.m, 1, d.Mk, d.m, 1, d.tMV, d.m, r, d.m, d.m);                              // V1 Mk0
+            vg_gemm_add(&g, d.V1s, d.m, 1, Hr[k], d.m, 1, d.tHV, d.m, r, d.m, d.m, 1, 0, hrn[k], ghs[k]);       // V1 H0
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(10);
+        // Ritz solve (forms H = T V1^T itself, Newton iteration); riders: the r x r sandwiches, and [C;C1;C2] of the fused step
+        VgGemmBatch gx;
+        vg_gemm_init(&gx);
+        if (ride) gx = c->ride_cc;
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            const int r = d.sub_r;
+            vg_gemm_add(&gx, d.tMV, d.m, 1, d.V1s, 1, d.m, d.tAM, r, r, r, d.m);                                // V1 Mk0 V1^T
+            vg_gemm_add(&gx, d.tHV, d.m, 1, d.V1s, 1, d.m, d.tAH, r, r, r, d.m);                                // V1 H0 V1^T
+        }
+        VgEigJob sj[2];
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            sj[k] = VgEigJob{nullptr, d.lam_s, d.Ws, nullptr, d.gwork2, d.rotlog2, d.roundlog2, d.counters2, d.sub_r, d.max_rounds,
+                             (long)vg_eigh_log_bytes(d.m), 0};
+            sj[k].Hl = d.Zs; sj[k].Hr = d.V1s; sj[k].hk = d.m;
+            sj[k].perm = d.perm2;
+            sj[k].err = d.status + 1;
+            sj[k].newton = 1;
+        }
+        VG_HIP(vg_eigh_launch(sj, 2, st, &gx));
+        if (ride) ride_stage = 2;
+        c->ride_pending = false;
+        VG_MARK(11);
+        const int ac_nslab = 1;
+        const long ac_slab = 3L * d1.sub_r * d2.sub_r;
+        {
+            // {C, C1, C2} V1_2^T, and the new range basis E_r = W V1 into the leading rows of QtPrev (next step's V)
+            vg_gemm_init(&g);
+            {
+                const int ic = vg_gemm_add(&g, C3, m2, 1, d2.V1s, 1, m2, c->tCV, d2.sub_r, (int)(3 * m1), d2.sub_r, (int)m2);
+                g.p[ic].a_nslab = ccn; g.p[ic].a_slab = ccs;
+            }
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                vg_gemm_add(&g, d.Ws, d.sub_r, 1, d.V1s, d.m, 1, d.QtPrev, d.m, d.sub_r, d.m, d.sub_r);
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+            VG_MARK(14);
+            vg_gemm_init(&g);
+            for (int q = 0; q < 3; ++q)
+                vg_gemm_add(&g, d1.V1s, m1, 1, c->tCV + (long)q * m1 * d2.sub_r, d2.sub_r, 1, c->tAC + (long)q * d1.sub_r * d2.sub_r, d2.sub_r,
+                            d1.sub_r, d2.sub_r, (int)m1);
+            VG_HIP(vg_gemm_launch(&g, st));
+            VG_MARK(15);
+        }
+        VgThinTail tt{};
+        tt.theta = c->theta; tt.n_total = (double)c->desc.n_total; tt.yy = yy_total;
+        tt.r1 = d1.sub_r; tt.r2 = d2.sub_r; tt.m1 = (int)m1; tt.m2 = (int)m2;
+        tt.W1 = d1.Ws; tt.W2 = d2.Ws; tt.lam1 = d1.lam_s; tt.lam2 = d2.lam_s;
+        tt.AM1 = d1.tAM; tt.AH1 = d1.tAH; tt.AM2 = d2.tAM; tt.AH2 = d2.tAH; tt.AC = c->tAC;
+        tt.ac_nslab = ac_nslab; tt.ac_slab = ac_slab;
+        tt.G1 = Gr[0]; tt.H1 = Hr[0]; tt.G2 = Gr[1]; tt.H2 = Hr[1];
+        tt.out = c->out; tt.hout = c->d_hout;
+        tt.peer_fail = (payload == c->payload && (c->n_ranks > 1 || c->comm || c->cb)) ? c->payload + c->payload_len : nullptr;
+        for (int k = 0; k < 2; ++k) { tt.jit[k] = c->d[k].jitter; tt.status[k] = c->d[k].status; tt.rcounters[k] = c->d[k].counters2; }
+#ifdef VGGP_DIAG
+        tt.stamps = reinterpret_cast<unsigned long long*>(c->tAC + 3 * VG_THIN_MAXR * VG_THIN_MAXR);
+#endif
+        VG_HIP(vg_thin_tail_launch(&tt, st));
+        VG_MARK(18);
+        return VGGP_OK;
+    }
     if (warm && subspace) {
         // ---- subspace start (numerically rank-deficient G, e.g. RBF: rank ~20 of 128).  S = d.Fp is the previous basis after
         // one Newton-Schulz step (partials ran with U = I), rows sorted by decreasing eigenvalue; its r leading rows V span
@@ -898,11 +1008,15 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // ---- HIP-graph cache: the launch sequence of a step is fixed for a plan, so it is captured once per
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
-       VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_COUNT };
+       VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_FINISH_WARM_T, VG_G_STEP_WARM_T,
+       VG_G_COUNT };
+static_assert(VG_G_COUNT <= 16, "vggp_ctx::gexec");
+// _T: thin chain (subspace start without a complement basis, thin.hip)
 // _S: subspace start (see finish_enqueue)
 // _X: warm start from the extrapolated basis; _XR: ... refined to first order before the eigensolver (see finish_enqueue)
 
 static void graphs_clear(vggp_ctx* c) {
+    (void)vg_quiesce(c);
     for (int i = 0; i < VG_G_COUNT; ++i) {
         if (c->gexec[i]) { (void)hipGraphExecDestroy(c->gexec[i]); c->gexec[i] = nullptr; }
         c->gkey[i] = VgGraphKey();
@@ -913,7 +1027,7 @@ template <typename F>
 static int run_graph(vggp_ctx* c, int which, const VgGraphKey& key, hipStream_t st, F enqueue, bool bypass = false) {
     if (!c->use_graph || c->prof || bypass) return enqueue();
     if (!c->gexec[which] || !(c->gkey[which] == key)) {
-        if (c->gexec[which]) { (void)hipGraphExecDestroy(c->gexec[which]); c->gexec[which] = nullptr; }
+        if (c->gexec[which]) { (void)vg_quiesce(c); (void)hipGraphExecDestroy(c->gexec[which]); c->gexec[which] = nullptr; }
         VG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         const int rc = enqueue();
         hipGraph_t graph = nullptr;
@@ -943,17 +1057,41 @@ static bool vg_extrapolate(const vggp_ctx* c) {
 
 // start-basis strategy of this step; switching the subspace mode on puts the identity into U (the partials then run a plain
 // Newton-Schulz clean-up of QtPrev through the extrapolation products) and drops stale _S graphs when the ranks moved
-struct VgStart { bool extrap, refine, subspace; };
-static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out) {
-    out->extrap = vg_extrapolate(c);
-    out->subspace = warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0;
+struct VgStart { bool extrap, refine, subspace, thin; };
+// The thin chain needs: ranks known and small, the leading rows of QtPrev valid, the step's payload owned by the context (its
+// read-outs re-run the finish half cold on the resident G, H, C), and no caller that wanted the full m-space state of a warm step.
+static bool vg_thin_ok(const vggp_ctx* c, bool own_payload) {
+    static const bool off = getenv("VGGP_NO_THIN") != nullptr;
+    if (off || c->thin_off || !own_payload || !c->desc.warm_start || (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) || !c->sub_next) return false;
+    for (int k = 0; k < 2; ++k) {
+        const VgDim& d = c->d[k];
+        if (!d.have_prev || !d.tMV || d.sub_r < 1 || d.sub_r > VG_THIN_MAXR || d.sub_r > d.thin_rows) return false;
+    }
+    return true;
+}
+// warm start possible?  After a thin step QtPrev holds range rows only: a step that cannot run thin then starts cold.
+static bool vg_warm(vggp_ctx* c, bool own_payload) {
+    bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
+    if (warm && (c->d[0].thin_rows < c->d[0].m || c->d[1].thin_rows < c->d[1].m) && !vg_thin_ok(c, own_payload)) {
+        c->warm_run = 0;
+        for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
+        warm = false;
+    }
+    return warm;
+}
+static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out, bool own_payload) {
+    out->thin = warm && vg_thin_ok(c, own_payload);
+    out->extrap = !out->thin && vg_extrapolate(c);
+    out->subspace = out->thin || (warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0);
     out->refine = warm && !out->subspace && vg_refine(c, out->extrap);
     c->sub_mode = out->subspace;
     if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
-        for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S})
-            if (c->gexec[v]) { (void)hipGraphExecDestroy(c->gexec[v]); c->gexec[v] = nullptr; c->gkey[v] = VgGraphKey(); }
+        for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S, (int)VG_G_FINISH_WARM_T, (int)VG_G_STEP_WARM_T})
+            if (c->gexec[v]) { (void)vg_quiesce(c); (void)hipGraphExecDestroy(c->gexec[v]); c->gexec[v] = nullptr; c->gkey[v] = VgGraphKey(); }
         c->sub_r_cap[0] = c->d[0].sub_r; c->sub_r_cap[1] = c->d[1].sub_r;
     }
+    c->cur_thin = out->thin;
+    c->cur_r[0] = c->d[0].sub_r; c->cur_r[1] = c->d[1].sub_r;
     return VGGP_OK;
 }
 
@@ -967,9 +1105,42 @@ static int set_theta(vggp_ctx* c, const double theta[5]) {
 }
 
 // host side of the end of a step: the only synchronisation, then unpack the pinned block
+// Completion of a single-rank step WITHOUT a HIP call: the last kernel of the step writes the 128-byte result block into pinned
+// host memory as one burst whose last word is the step's sequence number, so the host polls that word.  hipStreamSynchronize
+// returns only after the end-of-graph bookkeeping of the runtime (measured: ~8 us later); the stream itself keeps the order of
+// whatever is enqueued next.  Anything that must not overlap with the tail of the graph (destroying a graph exec, re-planning)
+// calls vg_quiesce first.  Falls back to the real synchronisation after 20 ms (a fault would otherwise spin for ever).
+static int vg_quiesce(vggp_ctx* c) {
+    if (c->poll_stream_valid) { c->poll_stream_valid = false; VG_HIP(hipStreamSynchronize(c->poll_stream)); }
+    return VGGP_OK;
+}
+static int vg_wait_step(vggp_ctx* c, hipStream_t st) {
+    static const bool nopoll = getenv("VGGP_NO_POLL") != nullptr;
+    if (nopoll || c->prof || c->comm || c->cb || c->n_ranks > 1) { c->poll_stream_valid = false; return vg_comm_wait(c, st); }
+    const volatile double* seq = &c->h_out->seq;
+    const double want = c->h_theta[5];
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spin = 0;; ++spin) {
+        if (*seq == want) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            c->poll_stream = st; c->poll_stream_valid = true;
+            return VGGP_OK;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 4095) == 4095) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > 0.02) break;
+        }
+    }
+    c->poll_stream_valid = false;
+    VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}
+
 static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vggp_info* info, hipStream_t st) {
     {
-        const int wrc = vg_comm_wait(c, st);          // (plain hipStreamSynchronize unless the context owns an RCCL communicator)
+        const int wrc = vg_wait_step(c, st);          // (single rank: polls the pinned result block; multi-rank: vg_comm_wait)
         if (wrc) {
             c->warm_run = 0;
             for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
@@ -1058,7 +1229,9 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     for (int k = 0; k < 2; ++k) {
         c->d[k].have_prev2 = c->d[k].have_prev;                // QtPrev2 <- previous basis (copied by the replay workgroups)
         c->d[k].have_prev = true;                              // QtPrev holds this step's basis
+        c->d[k].thin_rows = c->cur_thin ? c->cur_r[k] : c->d[k].m;      // ... all of it, or the range rows of a thin step
     }
+    c->last_thin = c->cur_thin;
     if (++c->warm_run >= 512) {                                // periodic cold restart: bounds the drift of orthogonality
         c->warm_run = 0;
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
@@ -1077,7 +1250,7 @@ extern "C" int vggp_elbo_partials(vggp_ctx* c, const double* Y, const double the
     c->nev = 0;
     const VgGraphKey key{Y, payload, 0.0};
     VgStart sp;
-    if ((rc = vg_start_prepare(c, c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev, st, &sp))) return rc;
+    if ((rc = vg_start_prepare(c, vg_warm(c, false), st, &sp, false))) return rc;
     const bool extrap = sp.extrap;
     // the Newton-Schulz step of the predicted basis accumulates into Fp: exactly once per prediction (a repeated partials
     // call without a finish in between runs un-captured without it)
@@ -1108,10 +1281,10 @@ static int elbo_finish_once(vggp_ctx* c, const double* payload, double yy_total,
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     int rc = set_theta(c, theta);
     if (rc) return rc;
-    const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
+    const bool warm = vg_warm(c, false);
     const VgGraphKey key{nullptr, payload, yy_total};
     VgStart sp;                                   // same state as at the matching vggp_elbo_partials call
-    if ((rc = vg_start_prepare(c, warm, st, &sp))) return rc;
+    if ((rc = vg_start_prepare(c, warm, st, &sp, false))) return rc;
     const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
     rc = run_graph(c, warm ? (subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
                             : VG_G_FINISH_COLD, key, st,
@@ -1150,10 +1323,10 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
     int rc = set_theta(c, theta);
     if (rc) return rc;
     c->nev = 0;
-    const bool warm = c->desc.warm_start && c->d[0].have_prev && c->d[1].have_prev;
+    const bool warm = vg_warm(c, true);
     VgStart sp;
-    if ((rc = vg_start_prepare(c, warm, st, &sp))) return rc;
-    const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
+    if ((rc = vg_start_prepare(c, warm, st, &sp, true))) return rc;
+    const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace, thin = sp.thin;
     const bool apply_ns = extrap && !c->pred_consumed;
     if (c->n_ranks > 1 || c->comm || c->cb) {
         // row-sharded job: partials graph -> the context's all-reduce of the packed payload (RCCL: enqueued on this stream)
@@ -1188,18 +1361,18 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         if (extrap) c->pred_consumed = true;
         c->have_partials = true;
         if ((rc = vg_allreduce(c, c->payload, c->payload_len + 1, st))) return rc;
-        rc = run_graph(c, warm ? (subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
+        rc = run_graph(c, warm ? (thin ? VG_G_FINISH_WARM_T : subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
                                 : VG_G_FINISH_COLD, kf, st,
-                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace); });
+                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace, thin); });
         if (rc) return rc;
         c->last_warm = warm; c->last_slabs = false; c->last_payload = c->payload; c->last_yy = yy_total;
         return finish_collect(c, elbo_out, grad_out, info, st);
     }
     const VgGraphKey key{Y, c->payload, yy_total};
-    rc = run_graph(c, warm ? (subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
+    rc = run_graph(c, warm ? (thin ? VG_G_STEP_WARM_T : subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
                             : VG_G_STEP_COLD, key, st, [&] {
         const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace, thin);
     }, extrap && !apply_ns);
     if (rc) return rc;
     if (extrap) c->pred_consumed = true;
@@ -1220,7 +1393,7 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
 // VGGP_FAST_READOUT=1 skips it (read-outs then carry the warm basis' accuracy).
 static int vg_accurate_state(vggp_ctx* c, hipStream_t st) {
     static const bool skip = getenv("VGGP_FAST_READOUT") != nullptr;
-    if (skip || !c->last_warm || c->acc_valid || !c->have_step) return VGGP_OK;
+    if ((skip && !c->last_thin) || !c->last_warm || c->acc_valid || !c->have_step) return VGGP_OK;     // (a thin step leaves no m-space state at all)
     if (c->last_payload != c->payload) return VGGP_OK;       // the caller owned the payload buffer (partials / finish API): not retained
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     if (c->last_slabs) {                                       // fused warm step: G, H, C are still split-K slabs
@@ -1248,7 +1421,8 @@ static int vg_accurate_state(vggp_ctx* c, hipStream_t st) {
     }
     if (status) { vg_set_error("accurate read-out: the cold eigensolve failed (status %d)", status); return status; }
     // QtPrev now holds the cold basis and QtPrev2 the warm basis of the SAME step: no extrapolation across that pair
-    for (int k = 0; k < 2; ++k) c->d[k].have_prev2 = false;
+    for (int k = 0; k < 2; ++k) { c->d[k].have_prev2 = false; c->d[k].thin_rows = c->d[k].m; }
+    c->last_thin = false;
     c->pred_consumed = false;
     c->acc_valid = true;
     return VGGP_OK;
@@ -1796,6 +1970,13 @@ extern "C" int vggp_zgrad(vggp_ctx* c, const double* Y, double* gz1, double* gz2
     const bool lead = !multi || c->rank == 0;
     VG_ENTER_DEVICE(c->device);
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    if (c->last_thin) {
+        // the inducing-point gradient contracts the FULL m-space state (beta, 1/D, Q): a thin step leaves none.  Rebuild it from
+        // the resident G, H, C (cold finish half) and keep this plan on the full chain from now on -- its caller trains Z.
+        c->thin_off = true;
+        const int rca = vg_accurate_state(c, st);
+        if (rca) return rca;
+    }
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     const bool pts[2] = {d1.basis == VGGP_BASIS_POINTS, d2.basis == VGGP_BASIS_POINTS};
@@ -1915,6 +2096,7 @@ extern "C" int vggp_debug_read_out(vggp_ctx* c, double* host8) {
 extern "C" int vggp_debug_read_gwork(vggp_ctx* c, int dim, int which, void* host, int64_t offset_doubles, int64_t bytes) {
     if (!c || !c->planned || dim < 0 || dim > 1) return VGGP_EINVAL;
     // which = 2: Gw (the matrix the main eigensolver started from), 3: the Ritz matrix Hs, 4: lam0, 5: the Ritz solve's counters (ints)
+    if (which == 6) { VG_HIP(hipMemcpy(host, c->tAC + offset_doubles, bytes, hipMemcpyDeviceToHost)); return VGGP_OK; }
     const double* src = which == 5 ? reinterpret_cast<const double*>(c->d[dim].counters2) : which == 2 ? c->d[dim].Gw : which == 3 ? c->d[dim].Hs : which == 4 ? c->d[dim].lam0 : which ? c->d[dim].gwork2 : c->d[dim].gwork;
     if (!src) return VGGP_EINVAL;
     VG_HIP(hipMemcpy(host, src + offset_doubles, bytes, hipMemcpyDeviceToHost));

@@ -257,6 +257,30 @@ struct VgMspace {
     const int* counters[2] = {nullptr, nullptr};
 };
 hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st);
+// "Thin" m-space stage of a subspace-start step (thin.hip): everything from the Ritz pairs to the pinned result block in ONE
+// single-workgroup kernel, range directions only (r1, r2 <= 32); all inputs at unit outputscale.
+#define VG_THIN_MAXR 32
+#define VG_THIN_MISS 1e-12     // admissible (tr G - sum of the Ritz values) per complement direction, relative to lam_max
+struct VgThinTail {
+    const double* theta;             // device [6]: ell1, ell2, s1, s2, v, sequence number
+    double n_total, yy;
+    int r1, r2, m1, m2;
+    const double *W1, *W2;           // [r][r] row-major: row j = Ritz vector j in V1 coordinates (sorted by decreasing Ritz value)
+    const double *lam1, *lam2;       // [r] Ritz values (unit scale, decreasing)
+    const double *AM1, *AH1, *AM2, *AH2;   // [r][r]: V1 Mk0 V1^T, V1 H0 V1^T
+    const double* AC;                // [3][r1][r2]: V1_1 {C, C1, C2} V1_2^T  (ac_nslab split-K slabs, ac_slab doubles apart)
+    int ac_nslab; long ac_slab;
+    const double *G1, *H1, *G2, *H2; // [m][m] reduced Gram pairs (only their diagonals are read: traces over ALL directions)
+    double* out;                     // device [8] (may be null)
+    VgHostOut* hout;                 // pinned result block
+    const double* peer_fail;         // see VgMspace
+    const double* jit[2];
+    const int* status[2];            // [2] per dimension: Cholesky status, eigensolver error bits
+    const int* rcounters[2];         // the Ritz solves' counters [4]
+    unsigned long long* stamps = nullptr;   // diagnostic builds (-DVGGP_DIAG): s_memrealtime stamps of the kernel's phases
+};
+hipError_t vg_thin_tail_launch(const VgThinTail* tt, hipStream_t st);
+hipError_t vg_thin_tail_setup();
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st);
 // inducing-point gradient (vggp_zgrad): weights of the gradient functional, and the row contraction with d kappa / d z
 hipError_t vg_zw_launch(const double* theta, int self, const double* lam_self, const double* lam_other, int m, int m_other,

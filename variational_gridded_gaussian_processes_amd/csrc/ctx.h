@@ -24,6 +24,9 @@ struct VgDim {
     double2* rotlog2 = nullptr;
     int *roundlog2 = nullptr, *counters2 = nullptr, *perm2 = nullptr;
     int sub_r = 0;                    // rows treated as the numerical range in the next step (0: subspace start off)
+    // thin chain (thin.hip): V1 Mk0, V1 H0 (r x m) and V1 Mk0 V1^T, V1 H0 V1^T (r x r)
+    double *tMV = nullptr, *tHV = nullptr, *tAM = nullptr, *tAH = nullptr;
+    int thin_rows = 0;                // leading rows of QtPrev that hold eigenvectors (m after a full solve, r after a thin step)
     bool have_prev = false, have_prev2 = false;     // QtPrev / QtPrev2 hold the bases of the last / the step before
 };
 
@@ -75,8 +78,8 @@ struct vggp_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork[VG_NFORK] = {}, ev_join[VG_NFORK] = {};
     bool use_graph = true;
-    hipGraphExec_t gexec[12] = {};
-    VgGraphKey gkey[12];
+    hipGraphExec_t gexec[16] = {};
+    VgGraphKey gkey[16];
     // what the accurate (cold) recompute of the read-outs needs from the last step (api.hip vg_accurate_state)
     bool last_warm = false, last_slabs = false, acc_valid = false;
     const double* last_payload = nullptr;
@@ -88,6 +91,11 @@ struct vggp_ctx {
     bool refine_next = false;
     bool sub_next = false;            // the last step's numerical ranks allow the subspace start
     int sub_r_cap[2] = {0, 0};        // ranks the _S graphs were captured with
+    double *tCV = nullptr, *tAC = nullptr;   // thin chain: {C, C1, C2} V1_2^T  [3 m1][r2]  and  V1_1 (.)  [3][r1][r2]
+    bool cur_thin = false;            // the step in flight runs the thin chain, with these ranks (vg_start_prepare -> finish_collect)
+    int cur_r[2] = {0, 0};
+    bool last_thin = false;           // the last finished step ran the thin chain: QtPrev holds r rows, the m-space state (beta, 1/D, E, F) is not there
+    bool thin_off = false;            // a caller needed the full m-space state of a warm step (vggp_zgrad): keep to the full chain from now on
     bool sub_mode = false;            // the current step uses the subspace start (U then holds the identity)         // the last step ended in the polish in both dimensions: refine the next start basis
     // the context's collective (comm.hip)
     int n_ranks = 1, rank = 0;
@@ -97,6 +105,8 @@ struct vggp_ctx {
     void* cb_user = nullptr;
     double* h_stage = nullptr;        // pinned staging of the callback transport
     long h_stage_count = 0;
+    hipStream_t poll_stream = nullptr;   // the last step's completion was seen in the pinned result block, not through the runtime:
+    bool poll_stream_valid = false;      // this stream may still be finishing its graph (api.hip vg_quiesce)
     long seq = 0;                     // step sequence number (h_theta[5] -> device theta[5] -> VgHostOut::seq)
     int warm_run = 0;                 // consecutive warm-started steps (periodic cold restart bounds orthogonality drift)
     // per-stage profiling (bench.py): event e[i] is recorded after stage i-1's launches
