@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   svgp_train_z      ms per optimiser iteration of an SVGP whose inducing points are trained (step + Z-gradient + in-place move)
   scattered         vggp_elbo_step_scattered: ms per step for 100 000 points that form no grid (B0 cells, m_d = 32)
   masked_md128      masked 2048 x 2048 grid, 30 % missing, m_d = 128 (M = 16384): ms per step of the dense M-space solver
+  masked_iter       the same grid through vggp_elbo_step_masked_iter (no M x M matrix): m_d = 128 and m_d = 256 (M = 65536)
   slab_1024x4096    the per-rank shape of BASELINE configs[3]: ms per step, and the projection kernel's MFMA fraction at that size
   kron_solve        BASELINE metric (ii): X = K1^{-1} Y K2^{-T} from Cholesky factors, GB/s and TFLOP/s
   factor_build      HBM-write rate of the factor kernel at m = n = 8192
@@ -490,6 +491,7 @@ def main():
             out["svgp_train_z"] = trainz_bench(eng, Y, yy, x1, x2, m)
             out["scattered"] = scattered_bench(eng)
             out["masked_md128"] = masked_md128_bench(eng, D)
+            out["masked_iter"] = masked_iter_bench(eng, D)
             out["kron_solve"] = kron_solve_bench(eng, 1024)
             out["factor_build"] = factor_build_bench(eng)
         if not args.no_cpu and world == 1 and not args.masked:
@@ -618,6 +620,39 @@ def masked_md128_bench(eng, D, n=2048, m=128, kind="matern12", steps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"n": n, "m_d": m, "M": m * m, "ms_per_step": dt * 1e3, "observed_points_per_s": nobs / dt, "elbo_last": e}
+
+
+def masked_iter_bench(eng, D, n=2048, kind="matern12", steps=3, n_probes=16):
+    """The masked step without M x M matrices (vggp_elbo_step_masked_iter: PCG with matricised Kronecker MVMs, Kronecker-eigenbasis
+    preconditioner, Lanczos quadrature, control-variate traces; fixed probes) on BASELINE configs[4]'s grid (2048 x 2048, 30 %
+    missing): m_d = 128 (M = 16384, where the dense solver needs 227 ms) with its deviation from the dense step, and m_d = 256
+    (M = 65536: the dense solver refuses above 16384)."""
+    import torch
+    X, y, x1, x2 = D.gen_grid(n, n)
+    del X
+    W = torch.tensor((np.random.default_rng(1).uniform(size=(n, n)) < 0.7).astype(np.float64), device=eng.device)
+    Ym = torch.tensor(y.reshape(n, n), device=eng.device) * W
+    nobs = float(W.sum().item())
+    out = {"n": n, "n_probes": n_probes}
+    for m in (128, 256):
+        mesh = np.linspace(0, 1, m + 1)
+        eng.plan(kind, "b0", mesh, x1, kind, "b0", mesh, x2)
+        yy = eng.sumsq(Ym)
+        e, gr, info = eng.elbo_step_masked_iter(Ym, W, nobs, yy, THETA0, n_probes=n_probes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            e, gr, info = eng.elbo_step_masked_iter(Ym, W, nobs, yy, [t * (1 + 0.01 * (k + 1)) for t in THETA0], n_probes=n_probes)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        r = {"M": m * m, "ms_per_step": dt * 1e3, "observed_points_per_s": nobs / dt, "pcg_iterations": info["rounds"][0], "elbo_last": e}
+        if m == 128:
+            th = [t * (1 + 0.01 * steps) for t in THETA0]
+            ed, gd, _ = eng.elbo_step_masked(Ym, W, nobs, yy, th)
+            r["elbo_rel_dev_vs_dense"] = abs(e - ed) / abs(ed)
+            r["grad_dev_vs_dense_rel_to_max"] = float(np.abs(gr - gd).max() / np.abs(gd).max())
+        out[f"m_d_{m}"] = r
+    return out
 
 
 def scattered_bench(eng, N=100000, m=32, kind="matern12", steps=10, warmup=3):

@@ -167,6 +167,18 @@ int vggp_elbo_finish(vggp_ctx* ctx, const double* payload, double yy_total, cons
  * and a second all-reduce of 21 scalars closes the gradient terms that are sums over grid rows. */
 int vggp_elbo_step_masked(vggp_ctx* ctx, const double* Ym, const double* W, double n_obs, double yy_obs,
                           const double theta[5], double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
+/* The masked step WITHOUT the M x M matrices -- for M = m1 m2 beyond the dense solver (M > 16384) or when O(M^3) is too slow:
+ * what gpytorch does for the reference above max_cholesky_size = 800 (`inv_matmul` by CG, `log_prob` by stochastic Lanczos
+ * quadrature, kronecker_structure.py:269, :273), here with matricised Kronecker MVMs  Sigma~ V = V + rho B1 (W^T o (B1^T V B2)) B2^T,
+ * the Kronecker-eigenbasis preconditioner P = I + rho p G1 (x) G2 (p = observed fraction), log|Sigma~| = log|P| + Lanczos
+ * quadrature of the PCG coefficients of n_probes FIXED Rademacher probes, and derivative traces as closed form + control-variate
+ * probe estimator.  Bitwise reproducible.  Stated tolerance against vggp_elbo_step_masked: ELBO 1e-5 relative, gradient 1e-4 of
+ * its largest component (n_probes = 16).  n_probes <= 0: 16; tol <= 0: 1e-10 (PCG residual, relative); max_iter <= 0: 100.
+ * Arguments otherwise as vggp_elbo_step_masked; single-rank contexts; info->rounds1 = PCG iterations, info->sweeps1 = probes.
+ * The dense read-outs (vggp_qv_masked, ...) need the dense step. */
+int vggp_elbo_step_masked_iter(vggp_ctx* ctx, const double* Ym, const double* W, double n_obs, double yy_obs,
+                               const double theta[5], int n_probes, double tol, int max_iter, double* elbo_out, double grad_out[5],
+                               vggp_info* info, void* stream);
 /* q(v) of the last masked step: mean and covariance diagonal, DEVICE [m1][m2]. */
 int vggp_qv_masked(vggp_ctx* ctx, double* mean, double* var, void* stream);
 /* posterior(x*) of the last masked step (kronecker_structure.py:199-230); arguments as vggp_posterior. */

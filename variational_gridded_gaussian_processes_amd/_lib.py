@@ -58,6 +58,7 @@ SYMBOLS = {
     "vggp_elbo_partials": (_I, [_P, _P, C.POINTER(_D), _P, _P]),
     "vggp_elbo_finish": (_I, [_P, _P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
     "vggp_elbo_step_masked": (_I, [_P, _P, _P, _D, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
+    "vggp_elbo_step_masked_iter": (_I, [_P, _P, _P, _D, _D, C.POINTER(_D), _I, _D, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
     "vggp_elbo_step_scattered": (_I, [_P, _P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(Info), _P]),
     "vggp_qv_masked": (_I, [_P, _P, _P, _P]),
     "vggp_qv": (_I, [_P, _P, _P, _P]),

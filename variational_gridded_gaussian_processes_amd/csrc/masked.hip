@@ -197,6 +197,9 @@ struct VgMasked {
     long M = 0, n1 = 0, n2 = 0;
     int m1 = 0, m2 = 0, nblk = 0;
     bool scattered = false;        // n1 == n2 == number of points: the [n2][n1] grid buffers shrink to per-point vectors
+    bool iter = false;             // iterative step (vggp_elbo_step_masked_iter): none of the M x M / pair-product buffers exist
+    void* imem = nullptr;          // its own workspace (VgIter, below)
+    size_t ibytes = 0;
     double *Sg, *Lg, *Xg, *Sinv, *R, *Phip, *DI, *Tmp;          // M x M (Phip: two of them; Tmp: 128 x M)
     double *PP1, *PP1v, *PP2, *PP2v, *T, *Tv;
     double *UB, *UV, *Zb, *Zv1, *Zv2, *B1s, *B2s;
@@ -217,18 +220,22 @@ static void vgm_layout(VgMasked& w, char* base, size_t& off) {
         off += count * sizeof(double);
         return p;
     };
-    const size_t M = w.M, MM = M * M, n1 = w.n1, n2 = w.n2, m1 = w.m1, m2 = w.m2;
-    w.Sg = take(MM); w.Lg = take(MM); w.Xg = take(MM); w.Sinv = take(MM); w.R = take(MM); w.Phip = take(2 * MM);
-    w.DI = take((size_t)w.nblk * VG_MB * VG_MB); w.Tmp = take((size_t)VG_MB * M);
-    w.PP1 = take(m1 * m1 * n1); w.PP1v = take(m1 * m1 * n1); w.PP2 = take(m2 * m2 * n2); w.PP2v = take(m2 * m2 * n2);
+    const size_t M = w.M, MM = w.iter ? 0 : M * M, n1 = w.n1, n2 = w.n2, m1 = w.m1, m2 = w.m2;
+    const size_t mmax2 = m1 > m2 ? m1 * m1 : m2 * m2;
+    if (!w.iter) {
+        w.Sg = take(MM); w.Lg = take(MM); w.Xg = take(MM); w.Sinv = take(MM); w.R = take(MM); w.Phip = take(2 * MM);
+        w.DI = take((size_t)w.nblk * VG_MB * VG_MB); w.Tmp = take((size_t)VG_MB * M);
+        w.PP1 = take(m1 * m1 * n1); w.PP1v = take(m1 * m1 * n1); w.PP2 = take(m2 * m2 * n2); w.PP2v = take(m2 * m2 * n2);
+    }
     const size_t grid = w.scattered ? n1 : n1 * n2;            // scattered: zb, zv1, zv2 are per-point vectors
-    w.T = take(w.scattered ? 256 * (m1 > m2 ? m1 * m1 : m2 * m2) : n1 * m2 * m2);      // scattered: split-K slabs of the small long-K products
-    w.Tv = take(w.scattered ? 256 : n1 * m2 * m2);
+    // T: the assembly's n1 x m2^2 buffer, later slab scratch of the long-K products (scattered / iterative: only the latter)
+    w.T = take((w.scattered || w.iter) ? std::max<size_t>(256 * mmax2, 64 * n1) : n1 * m2 * m2);
+    w.Tv = take((w.scattered || w.iter) ? 256 : n1 * m2 * m2);
     w.UB = take(m1 * n2); w.UV = take(m1 * n2); w.Zb = take(grid); w.Zv1 = take(grid); w.Zv2 = take(grid);
     w.B1s = take(m1 * n1); w.B2s = take(m2 * n2);
     w.nb1 = take(n1); w.nb2 = take(n2); w.hv1 = take(n1); w.hv2 = take(n2); w.wn1 = take(n2);
     const size_t wn2len = w.scattered ? 0 : n1;                 // (scattered: the all-reduce payload is C, C1, C2 | R3, the same
-    w.mpay = take(2 * m2 * m2 + 3 * M + wn2len + 3 * MM);       //  length on every rank whatever its number of points)
+    w.mpay = take(2 * m2 * m2 + 3 * M + wn2len + 3 * MM + 8);   //  length on every rank whatever its number of points)
     w.wn2 = base ? w.mpay + 2 * m2 * m2 + 3 * M : nullptr;
     w.R3 = base ? w.wn2 + wn2len : nullptr;
     w.scal = take(32);
@@ -239,14 +246,16 @@ static void vgm_layout(VgMasked& w, char* base, size_t& off) {
     w.cholstatus = reinterpret_cast<int*>(take(8));
 }
 
-static int vgm_prepare(vggp_ctx* c) {
+static int vgm_prepare(vggp_ctx* c, bool iter = false) {
     VgMasked* w = reinterpret_cast<VgMasked*>(c->masked);
     if (!w) { w = new VgMasked(); c->masked = w; }
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     const bool sc = (c->desc.flags & VGGP_FLAG_SCATTERED) != 0;
-    if (w->mem && w->M == m1 * m2 && w->n1 == c->desc.n1 && w->n2 == c->desc.n2 && w->m1 == m1 && w->scattered == sc) return VGGP_OK;
+    if (w->mem && w->M == m1 * m2 && w->n1 == c->desc.n1 && w->n2 == c->desc.n2 && w->m1 == m1 && w->scattered == sc && w->iter == iter)
+        return VGGP_OK;
     if (w->mem) { VG_HIP(hipFree(w->mem)); w->mem = nullptr; }
-    w->M = m1 * m2; w->m1 = (int)m1; w->m2 = (int)m2; w->n1 = c->desc.n1; w->n2 = c->desc.n2; w->scattered = sc;
+    if (w->imem) { VG_HIP(hipFree(w->imem)); w->imem = nullptr; w->ibytes = 0; }
+    w->M = m1 * m2; w->m1 = (int)m1; w->m2 = (int)m2; w->n1 = c->desc.n1; w->n2 = c->desc.n2; w->scattered = sc; w->iter = iter;
     w->nblk = (int)((w->M + VG_MB - 1) / VG_MB);
     size_t off = 0;
     vgm_layout(*w, nullptr, off);
@@ -262,6 +271,7 @@ void vg_masked_free(vggp_ctx* c) {
     VgMasked* w = reinterpret_cast<VgMasked*>(c->masked);
     if (!w) return;
     if (w->mem) (void)hipFree(w->mem);
+    if (w->imem) (void)hipFree(w->imem);
     delete w;
     c->masked = nullptr;
 }
@@ -354,6 +364,50 @@ int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st) {
     return VGGP_OK;
 }
 
+// ---- pieces shared by the dense and the iterative masked step ----------------------------------------------------------------
+// column statistics of the whitened factors: |b_i|^2, v_i . b_i, and their mask-weighted sums along the other axis
+static int vgm_colstats(vggp_ctx* c, VgMasked& w, const double* W, hipStream_t st) {
+    const long m1 = c->desc.m1, m2 = c->desc.m2, n1 = c->desc.n1, n2 = c->desc.n2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const double *B1 = d1.BV, *V1 = d1.BV + m1 * n1, *B2 = d2.BV, *V2 = d2.BV + m2 * n2;
+    VGM_LAUNCH1D(vgm_coldot_kernel, n1, st, B1, B1, (int)m1, n1, w.nb1);
+    VGM_LAUNCH1D(vgm_coldot_kernel, n2, st, B2, B2, (int)m2, n2, w.nb2);
+    VGM_LAUNCH1D(vgm_coldot_kernel, n1, st, V1, B1, (int)m1, n1, w.hv1);
+    VGM_LAUNCH1D(vgm_coldot_kernel, n2, st, V2, B2, (int)m2, n2, w.hv2);
+    {
+        const long mm = m2 * m2;                                // w.T (written by the assembly later / slab scratch) is the scratch
+        const int nslab = (int)(mm < 64 ? mm : 64);
+        hipLaunchKernelGGL(vgm_wcol_part_kernel, dim3((unsigned)((n1 + 255) / 256), (unsigned)nslab), dim3(256), 0, st, W, w.nb2,
+                           n1, n2, nslab, w.T);
+        VGM_LAUNCH1D(vgm_wcol_sum_kernel, n1, st, w.T, n1, nslab, w.wn2);           // partial over this rank's rows
+    }
+    hipLaunchKernelGGL(vgm_wrow_kernel, dim3((unsigned)n2), dim3(256), 0, st, W, w.nb1, n1, n2, w.wn1);
+    VG_HIP(hipGetLastError());
+    return VGGP_OK;
+}
+// everything of the gradient that needs a0 = Sigma~^-1 c0 only (w.a0 as an m1 x m2 matrix) and the two PT matrices
+static int vgm_a0_terms(vggp_ctx* c, VgMasked& w, hipStream_t st) {
+    const long m1 = c->desc.m1, m2 = c->desc.m2, n1 = c->desc.n1, n2 = c->desc.n2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const double *B1 = d1.BV, *V1 = d1.BV + m1 * n1, *B2 = d2.BV, *V2 = d2.BV + m2 * n2;
+    int rc;
+    // Mk1 A0, A0 Mk2 ; UB = A0 B2, UV = A0 V2 ; Zb^T = UB^T B1, Zv1^T = UB^T V1, Zv2^T = UV^T B1   ([n2][n1] like W)
+    if ((rc = gemm1(d1.Mk, m1, 1, w.a0, m2, 1, w.MkA1, (int)m2, (int)m1, (int)m2, (int)m1, st))) return rc;
+    if ((rc = gemm1(w.a0, m2, 1, d2.Mk, m2, 1, w.MkA2, (int)m2, (int)m1, (int)m2, (int)m2, st))) return rc;
+    if ((rc = gemm1(w.a0, m2, 1, B2, n2, 1, w.UB, (int)n2, (int)m1, (int)n2, (int)m2, st))) return rc;
+    if ((rc = gemm1(w.a0, m2, 1, V2, n2, 1, w.UV, (int)n2, (int)m1, (int)n2, (int)m2, st))) return rc;
+    if ((rc = gemm1(w.UB, 1, n2, B1, n1, 1, w.Zb, (int)n1, (int)n2, (int)n1, (int)m1, st))) return rc;
+    if ((rc = gemm1(w.UB, 1, n2, V1, n1, 1, w.Zv1, (int)n1, (int)n2, (int)n1, (int)m1, st))) return rc;
+    if ((rc = gemm1(w.UV, 1, n2, B1, n1, 1, w.Zv2, (int)n1, (int)n2, (int)n1, (int)m1, st))) return rc;
+    // PT_d = B_d diag(w) B_d^T
+    VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * n1, st, B1, w.wn2, (int)m1, n1, w.B1s);
+    VGM_LAUNCH1D(vgm_scalecols_kernel, m2 * n2, st, B2, w.wn1, (int)m2, n2, w.B2s);
+    // (short outputs, long reductions: split-K with the T buffer -- free by now -- as slab scratch)
+    if ((rc = gemm_longk(w.B1s, n1, 1, B1, 1, n1, w.PT1, (int)m1, (int)m1, (int)n1, w.T, st))) return rc;
+    if ((rc = gemm_longk(w.B2s, n2, 1, B2, 1, n2, w.PT2, (int)m2, (int)m2, (int)n2, w.T, st))) return rc;
+    return VGGP_OK;
+}
+
 static int dense_chol_inverse(vggp_ctx* c, VgMasked& w, hipStream_t st) {
     (void)c;
     VgDenseChol d{w.Sg, w.Lg, w.Xg, w.DI, w.Tmp, w.cholscratch, w.choljit, w.cholstatus, w.M, w.Sinv};
@@ -388,19 +442,7 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     const double *B1 = d1.BV, *V1 = d1.BV + m1 * n1, *B2 = d2.BV, *V2 = d2.BV + m2 * n2;
     const double *C0 = w.mpay + 2 * m2 * m2, *C1 = C0 + M, *C2 = C1 + M;
 
-    // column statistics
-    VGM_LAUNCH1D(vgm_coldot_kernel, n1, st, B1, B1, (int)m1, n1, w.nb1);
-    VGM_LAUNCH1D(vgm_coldot_kernel, n2, st, B2, B2, (int)m2, n2, w.nb2);
-    VGM_LAUNCH1D(vgm_coldot_kernel, n1, st, V1, B1, (int)m1, n1, w.hv1);
-    VGM_LAUNCH1D(vgm_coldot_kernel, n2, st, V2, B2, (int)m2, n2, w.hv2);
-    {
-        const long mm = m2 * m2;                                // w.T ([m2 m2][n1], written by the assembly below) is the scratch
-        const int nslab = (int)(mm < 64 ? mm : 64);
-        hipLaunchKernelGGL(vgm_wcol_part_kernel, dim3((unsigned)((n1 + 255) / 256), (unsigned)nslab), dim3(256), 0, st, W, w.nb2,
-                           n1, n2, nslab, w.T);
-        VGM_LAUNCH1D(vgm_wcol_sum_kernel, n1, st, w.T, n1, nslab, w.wn2);           // partial over this rank's rows
-    }
-    hipLaunchKernelGGL(vgm_wrow_kernel, dim3((unsigned)n2), dim3(256), 0, st, W, w.nb1, n1, n2, w.wn1);
+    if ((rc = vgm_colstats(c, w, W, st))) return rc;
     // assembly (partial over this rank's rows: T sums over j, R = PP1 T is linear in T)
     VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * n2, st, B2, B2, (int)m2, (int)m2, n2, w.PP2);
     VGM_LAUNCH1D(vgm_pairprod_kernel, m2 * m2 * n2, st, B2, V2, (int)m2, (int)m2, n2, w.PP2v);
@@ -421,20 +463,8 @@ extern "C" int vggp_elbo_step_masked(vggp_ctx* c, const double* Ym, const double
     if ((rc = dense_chol_inverse(c, w, st))) return rc;
     // a0 = Sinv c0 ; A0 = mat(a0) (m1 x m2)
     if ((rc = gemm1(w.Sinv, M, 1, C0, 1, 1, w.a0, 1, (int)M, 1, (int)M, st))) return rc;
-    // Mk1 A0, A0 Mk2 ; UB = A0 B2, UV = A0 V2 ; Zb^T = UB^T B1, Zv1^T = UB^T V1, Zv2^T = UV^T B1   ([n2][n1] like W)
-    if ((rc = gemm1(d1.Mk, m1, 1, w.a0, m2, 1, w.MkA1, (int)m2, (int)m1, (int)m2, (int)m1, st))) return rc;
-    if ((rc = gemm1(w.a0, m2, 1, d2.Mk, m2, 1, w.MkA2, (int)m2, (int)m1, (int)m2, (int)m2, st))) return rc;
-    if ((rc = gemm1(w.a0, m2, 1, B2, n2, 1, w.UB, (int)n2, (int)m1, (int)n2, (int)m2, st))) return rc;
-    if ((rc = gemm1(w.a0, m2, 1, V2, n2, 1, w.UV, (int)n2, (int)m1, (int)n2, (int)m2, st))) return rc;
-    if ((rc = gemm1(w.UB, 1, n2, B1, n1, 1, w.Zb, (int)n1, (int)n2, (int)n1, (int)m1, st))) return rc;
-    if ((rc = gemm1(w.UB, 1, n2, V1, n1, 1, w.Zv1, (int)n1, (int)n2, (int)n1, (int)m1, st))) return rc;
-    if ((rc = gemm1(w.UV, 1, n2, B1, n1, 1, w.Zv2, (int)n1, (int)n2, (int)n1, (int)m1, st))) return rc;
-    // PT_d = B_d diag(w) B_d^T, partial traces of Sinv
-    VGM_LAUNCH1D(vgm_scalecols_kernel, m1 * n1, st, B1, w.wn2, (int)m1, n1, w.B1s);
-    VGM_LAUNCH1D(vgm_scalecols_kernel, m2 * n2, st, B2, w.wn1, (int)m2, n2, w.B2s);
-    // (short outputs, long reductions: split-K with the assembly's T buffer -- free by now -- as slab scratch)
-    if ((rc = gemm_longk(w.B1s, n1, 1, B1, 1, n1, w.PT1, (int)m1, (int)m1, (int)n1, w.T, st))) return rc;
-    if ((rc = gemm_longk(w.B2s, n2, 1, B2, 1, n2, w.PT2, (int)m2, (int)m2, (int)n2, w.T, st))) return rc;
+    if ((rc = vgm_a0_terms(c, w, st))) return rc;
+    // partial traces of Sinv
     VGM_LAUNCH1D(vgm_ptrace_kernel, m1 * m1, st, w.Sinv, (int)m1, (int)m2, 1, w.PTS1);
     VGM_LAUNCH1D(vgm_ptrace_kernel, m2 * m2, st, w.Sinv, (int)m1, (int)m2, 2, w.PTS2);
     // reductions
@@ -941,5 +971,545 @@ extern "C" int vggp_qv_cov_masked(vggp_ctx* c, double* cov, void* stream) {
     VGM_LAUNCH1D(vgm_scale_e_kernel, M * M, st, cov, M * M, c->theta, e1, e2);
     VG_HIP(hipGetLastError());
     VG_HIP(hipStreamSynchronize(st));
+    return VGGP_OK;
+}
+
+// ================================================================================================================================
+// Iterative masked step: what gpytorch does for the reference above max_cholesky_size = 800 --
+// `inv_matmul` by conjugate gradients, `log_prob` by stochastic Lanczos quadrature (kronecker_structure.py:269, :273) -- rebuilt for
+// the Kronecker structure, preconditioned and with FIXED probes, so that no M x M matrix exists and M = m1 m2 is not limited by
+// O(M^2) memory or O(M^3) time.  Specification: oracle/kron.py elbo_step_masked_iter (tolerances against the dense step: ELBO 1e-5,
+// gradient 1e-4 of its largest component).
+//
+//   operator        Sigma~ V = V + rho B1 (W^T o (B1^T V B2)) B2^T          V: m1 x m2; four MFMA GEMMs + one mask pass over n1 x n2
+//   block vectors   nbc = 1 + n_probes right-hand sides, stored interleaved [m1][nbc][m2]: then every GEMM of the operator is ONE
+//                   plain GEMM for the whole block ([m1][(nbc m2)] as B operand, [(m1 nbc)][m2] / [(n1 nbc)][.] as A operand)
+//   preconditioner  P = I + rho p G1 (x) G2 (p = observed fraction): E[Phi~] for an unstructured mask, diagonal in the Kronecker
+//                   eigenbasis Q1 (x) Q2 of the full-grid path (the step's own eigensolver), applied by four m x m x m GEMMs
+//   log|Sigma~|     log|P| + mean_z M e1^T log(T_z) e1, T_z = Lanczos tridiagonal of P^-1/2 Sigma~ P^-1/2 from the PCG coefficients of
+//                   the probe z = P^1/2 z0, z0 Rademacher from a counter-based hash (bitwise reproducible)
+//   traces          tr(Sigma~^-1 D) = tr(P^-1 D) [closed form, two GEMMs over the mask] + mean_z (Sigma~^-1 z - P^-1 z)^T D P^-1 z
+// ================================================================================================================================
+struct VgIter {
+    int nbc = 0, maxit = 0;
+    double *Wt;                                   // [n1][n2] mask, transposed once per step
+    double *X, *R, *Zp, *Pd, *AP, *Wz, *Tm, *Tm2; // block vectors [m1][nbc][m2]
+    double *T1;                                   // [n1][nbc][max(m1, m2)]
+    double *F0, *F1, *F2;                         // fields [n1][nbc][n2]
+    double *alh, *beh;                            // [maxit][nbc] PCG coefficients
+    double *col;                                  // per-column scalars: [0] rz, [1] pAp, [2] r0^2, [3] rr, [4] alpha, [5] beta, [6] active, [7] k
+    double *Rr1, *Rr2, *Rv1, *Rv2, *RR1, *RRV1, *RR2, *RRV2, *TW, *TWv, *Ex;   // rotated factors and the exact traces' temporaries
+    double *dg1, *dg2, *Tq;                       // diag(Q^T Mk Q), m x m temporary
+    double *ts;                                   // [32] scalars
+    int* nact;                                    // device word: number of active columns
+    int* h_nact;                                  // pinned
+};
+
+__device__ __forceinline__ unsigned long long vgi_mix(unsigned long long x) {       // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+// block[a][c][b] = +-1 for probe columns c >= 1 (counter-based: the same probes on every device, every run), 0 for column 0
+__global__ void vgi_probe_kernel(double* blk, int m1, int nbc, int m2, unsigned long long seed) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)m1 * nbc * m2) return;
+    const int b = (int)(idx % m2), c = (int)((idx / m2) % nbc), a = (int)(idx / ((long)m2 * nbc));
+    const unsigned long long h = vgi_mix(seed ^ vgi_mix(((unsigned long long)c << 40) ^ ((unsigned long long)a * m2 + b)));
+    blk[idx] = c == 0 ? 0.0 : ((h >> 17) & 1ULL ? 1.0 : -1.0);
+}
+// out[a][c][b] = in[a][c][b] * f(dP[a][b]),  dP = 1 + rho p max(lam1,0) max(lam2,0);  mode 0: 1/dP, 1: sqrt(dP), 2: 1/sqrt(dP)
+__global__ void vgi_scale_kernel(const double* in, double* out, const double* lam1, const double* lam2, const double* theta, double p,
+                                 int m1, int nbc, int m2, int mode, int c_from) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)m1 * nbc * m2) return;
+    const int b = (int)(idx % m2), c = (int)((idx / m2) % nbc), a = (int)(idx / ((long)m2 * nbc));
+    const double rho = theta[2] * theta[3] / theta[4];
+    const double d = 1.0 + rho * p * fmax(lam1[a], 0.0) * fmax(lam2[b], 0.0);
+    const double f = mode == 0 ? 1.0 / d : (mode == 1 ? sqrt(d) : 1.0 / sqrt(d));
+    out[idx] = c >= c_from ? in[idx] * f : 0.0;
+}
+__global__ void vgi_transpose_kernel(const double* W, long n1, long n2, double* Wt) {      // Wt[i][j] = W[j][i]
+    __shared__ double tile[32][33];
+    const long i0 = (long)blockIdx.x * 32, j0 = (long)blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const long j = j0 + r, i = i0 + threadIdx.x;
+        tile[r][threadIdx.x] = (j < n2 && i < n1) ? W[j * n1 + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const long i = i0 + r, j = j0 + threadIdx.x;
+        if (i < n1 && j < n2) Wt[i * n2 + j] = tile[threadIdx.x][r];
+    }
+}
+// F[i][c][j] *= Wt[i][j]
+__global__ void vgi_mask_kernel(double* F, const double* Wt, long n1, int nbc, long n2) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n1 * nbc * n2) return;
+    const long j = idx % n2, i = idx / (n2 * nbc);
+    F[idx] *= Wt[i * n2 + j];
+}
+// column c of the block vector <- the m1 x m2 matrix src (mode 0) / the matrix dst <- column c (mode 1)
+__global__ void vgi_col_kernel(double* blk, double* mat, int m1, int nbc, int m2, int c, int mode) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)m1 * m2) return;
+    const int a = (int)(idx / m2), b = (int)(idx - (long)a * m2);
+    double* e = blk + ((long)a * nbc + c) * m2 + b;
+    if (mode == 0) *e = mat[idx]; else mat[idx] = *e;
+}
+// per-column dot products of block vectors: out0[c] = <A, B>_c, out1[c] = <C, D>_c (second pair optional); one workgroup per
+// column, fixed summation order
+__global__ __launch_bounds__(256) void vgi_coldots_kernel(const double* A, const double* B, const double* C, const double* D, int m1, int nbc,
+                                                          int m2, double* out0, double* out1) {
+    __shared__ double red[8];
+    const int c = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (long e = threadIdx.x; e < (long)m1 * m2; e += 256) {
+        const long a = e / m2, b = e - a * m2, o = (a * nbc + c) * m2 + b;
+        s0 += A[o] * B[o];
+        if (C) s1 += C[o] * D[o];
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s0; red[4 + (threadIdx.x >> 6)] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out0[c] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (out1) out1[c] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+// PCG scalar logic, one lane per column.  col: [0] rz, [1] pAp, [2] r0^2, [3] rr, [4] alpha, [5] beta, [6] active, [7] k (rows of nbc)
+__global__ void vgi_pcg_scalars_kernel(double* col, int nbc, int phase, int it, double tol, double* alh, double* beh, int* nact) {
+    const int c = threadIdx.x;
+    double *rz = col, *pAp = col + nbc, *r02 = col + 2 * nbc, *rr = col + 3 * nbc, *al = col + 4 * nbc, *be = col + 5 * nbc,
+           *act = col + 6 * nbc, *kc = col + 7 * nbc;
+    if (c < nbc) {
+        if (phase == 0) {                 // start: rz, rr hold <r, P^-1 r>, <r, r>
+            r02[c] = rr[c]; act[c] = rr[c] > 0.0 ? 1.0 : 0.0; kc[c] = 0.0;
+        } else if (phase == 1) {          // after pAp
+            const double a = (act[c] != 0.0 && pAp[c] > 0.0) ? rz[c] / pAp[c] : 0.0;
+            al[c] = a; alh[(long)it * nbc + c] = a;
+        } else {                          // after the new <r, P^-1 r> (in pAp's slot is NOT touched: rz_new arrives in be's slot)
+            const double rzn = be[c];
+            const double b = (act[c] != 0.0 && rz[c] > 0.0) ? rzn / rz[c] : 0.0;
+            be[c] = b; beh[(long)it * nbc + c] = b;
+            rz[c] = rzn;
+            if (act[c] != 0.0) kc[c] += 1.0;
+            if (!(rr[c] > tol * tol * r02[c])) act[c] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (phase != 1 && threadIdx.x == 0) { int n = 0; for (int k = 0; k < nbc; ++k) n += act[k] != 0.0 ? 1 : 0; *nact = n; }
+}
+// x += alpha_c p, r -= alpha_c ap    /    p = z + beta_c p
+__global__ void vgi_update_kernel(double* X, double* R, double* Pd, const double* AP, const double* Zp, const double* col, int m1, int nbc,
+                                  int m2, int phase) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)m1 * nbc * m2) return;
+    const int c = (int)((idx / m2) % nbc);
+    if (phase == 1) { const double a = col[4 * nbc + c]; X[idx] += a * Pd[idx]; R[idx] -= a * AP[idx]; }
+    else Pd[idx] = Zp[idx] + col[5 * nbc + c] * Pd[idx];
+}
+// out = a + rho b   (AP = P + rho Phi~ P)
+__global__ void vgi_axpy_rho_kernel(const double* a, const double* b, const double* theta, long n, double* out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = a[idx] + (theta[2] * theta[3] / theta[4]) * b[idx];
+}
+__global__ void vgi_sub_kernel(const double* a, const double* b, long n, double* out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = a[idx] - b[idx];
+}
+__global__ void vgi_mul_kernel(const double* a, const double* b, long n, double* out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = a[idx] * b[idx];
+}
+// out[a] = sum_k A[a][k] B[a][k]
+__global__ void vgi_rowdot_kernel(const double* A, const double* B, int m, double* out) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += A[(long)a * m + k] * B[(long)a * m + k];
+    out[a] = s;
+}
+// Gauss quadrature of log on the Lanczos tridiagonal of each probe column (implicit QL with shifts, first eigenvector components
+// only): one lane per probe, k <= VGI_MAXIT.  out[c - 1] = M sum_j tau_j^2 log(theta_j)
+#define VGI_MAXIT 128
+__global__ void vgi_slq_kernel(const double* alh, const double* beh, const double* col, int nbc, double Mdim, double* out, int* fail) {
+    const int c = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nbc) return;
+    const int k = (int)col[7 * nbc + c];
+    double d[VGI_MAXIT], e[VGI_MAXIT], z[VGI_MAXIT];
+    for (int j = 0; j < k; ++j) {
+        const double a = alh[(long)j * nbc + c];
+        d[j] = 1.0 / a + (j > 0 ? beh[(long)(j - 1) * nbc + c] / alh[(long)(j - 1) * nbc + c] : 0.0);
+        e[j] = j + 1 < k ? sqrt(beh[(long)j * nbc + c]) / a : 0.0;
+        z[j] = j == 0 ? 1.0 : 0.0;
+    }
+    for (int l = 0; l < k; ++l) {
+        int iter = 0, mm;
+        do {
+            for (mm = l; mm < k - 1; ++mm) {
+                const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+                if (fabs(e[mm]) <= 1e-16 * dd) break;
+            }
+            if (mm != l) {
+                if (iter++ == 60) { atomicOr(fail, 1); break; }
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = hypot(g, 1.0);
+                g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                double s = 1.0, cc = 1.0, p = 0.0;
+                int i;
+                for (i = mm - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = cc * e[i];
+                    e[i + 1] = (r = hypot(f, g));
+                    if (r == 0.0) { d[i + 1] -= p; e[mm] = 0.0; break; }
+                    s = f / r; cc = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * cc * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = cc * r - b;
+                    f = z[i + 1];
+                    z[i + 1] = s * z[i] + cc * f;
+                    z[i] = cc * z[i] - s * f;
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[mm] = 0.0;
+            }
+        } while (mm != l);
+    }
+    double acc = 0.0;
+    for (int j = 0; j < k; ++j) { if (!(d[j] > 0.0)) atomicOr(fail, 2); acc += z[j] * z[j] * log(d[j]); }
+    out[c - 1] = Mdim * acc;
+}
+// scalars of the iterative step -> the slots of the dense step's reduction buffer (vgm_final_kernel reads them)
+//   ts: [0] sum log dP, [1] sum of the quadratures, [2] exact tr(P^-1 Phi), [3] est BB, [4] exact V1, [5] est 1a, [6] est 1b,
+//       [7] exact V2, [8] est 2a, [9] est 2b, [10] exact Mk1, [11] est Mk1, [12] exact Mk2, [13] est Mk2
+__global__ void vgi_combine_kernel(const double* ts, const double* theta, double Mdim, int nz, double* scal) {
+    if (threadIdx.x != 0) return;
+    const double rho = theta[2] * theta[3] / theta[4], inz = 1.0 / nz;
+    scal[RJ_LOGDET] = 0.5 * (ts[0] + ts[1] * inz);
+    const double trSP = ts[2] + ts[3] * inz;
+    scal[RJ_TRS] = Mdim - rho * trSP;
+    scal[RJ_SPHI1] = 0.5 * (2.0 * ts[4] + (ts[5] + ts[6]) * inz);
+    scal[RJ_SPHI2] = 0.5 * (2.0 * ts[7] + (ts[8] + ts[9]) * inz);
+    scal[RJ_MK1PTS] = ts[10] + ts[11] * inz;
+    scal[RJ_MK2PTS] = ts[12] + ts[13] * inz;
+}
+// out[0] = sum_{a,b} f(dP[a,b]) * E[a][b] (E null: 1) * (dg1 ? dg1[a] : 1) * (dg2 ? dg2[b] : 1);  mode 0: f = 1/dP, 1: f = log dP
+__global__ __launch_bounds__(256) void vgi_dpsum_kernel(const double* lam1, const double* lam2, const double* theta, double p, int m1, int m2,
+                                                        const double* E, const double* dg1, const double* dg2, int mode, double* out) {
+    __shared__ double red[4];
+    const double rho = theta[2] * theta[3] / theta[4];
+    double s = 0.0;
+    for (long e = threadIdx.x; e < (long)m1 * m2; e += 256) {
+        const int a = (int)(e / m2), b = (int)(e - (long)a * m2);
+        const double d = 1.0 + rho * p * fmax(lam1[a], 0.0) * fmax(lam2[b], 0.0);
+        double v = mode == 0 ? 1.0 / d : log(d);
+        if (E) v *= E[e];
+        if (dg1) v *= dg1[a];
+        if (dg2) v *= dg2[b];
+        s += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// out[0] = sum over i, c >= 1, j of Wt[i][j] Fa[i][c][j] Fb[i][c][j]   (two stages, fixed order)
+__global__ __launch_bounds__(256) void vgi_fieldsum_part_kernel(const double* Fa, const double* Fb, const double* Wt, long n1, int nbc, long n2,
+                                                                double* part) {
+    __shared__ double red[4];
+    const long total = n1 * nbc * n2;
+    double s = 0.0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long j = idx % n2, c = (idx / n2) % nbc, i = idx / (n2 * nbc);
+        if (c >= 1) s += Wt[i * n2 + j] * Fa[idx] * Fb[idx];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void vgi_sum_kernel(const double* part, int n, double* out, int c_from) {           // out[0] = sum_{k >= c_from} part[k]
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int k = c_from; k < n; ++k) s += part[k];
+    out[0] = s;
+}
+
+static int vgi_prepare(vggp_ctx* c, VgMasked& w, VgIter& it, int nbc, int maxit) {
+    const size_t m1 = w.m1, m2 = w.m2, n1 = w.n1, n2 = w.n2, M = w.M, mx = std::max(m1, m2);
+    size_t off = 0;
+    char* base = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        off = 0;
+        auto take = [&](size_t count) {
+            off = (off + 255) & ~size_t(255);
+            double* p = base ? reinterpret_cast<double*>(base + off) : nullptr;
+            off += count * sizeof(double);
+            return p;
+        };
+        it.Wt = take(n1 * n2);
+        it.X = take(M * nbc); it.R = take(M * nbc); it.Zp = take(M * nbc); it.Pd = take(M * nbc); it.AP = take(M * nbc);
+        it.Wz = take(M * nbc); it.Tm = take(M * nbc); it.Tm2 = take(M * nbc);
+        it.T1 = take(n1 * nbc * mx);
+        it.F0 = take(n1 * nbc * n2); it.F1 = take(n1 * nbc * n2); it.F2 = take(n1 * nbc * n2);
+        it.alh = take((size_t)maxit * nbc); it.beh = take((size_t)maxit * nbc);
+        it.col = take(8 * (size_t)nbc);
+        it.Rr1 = take(m1 * n1); it.Rv1 = take(m1 * n1); it.RR1 = take(m1 * n1); it.RRV1 = take(m1 * n1);
+        it.Rr2 = take(m2 * n2); it.Rv2 = take(m2 * n2); it.RR2 = take(m2 * n2); it.RRV2 = take(m2 * n2);
+        it.TW = take(n1 * m2); it.TWv = take(n1 * m2); it.Ex = take(M);
+        it.dg1 = take(m1); it.dg2 = take(m2); it.Tq = take(mx * mx);
+        it.ts = take(64);
+        it.nact = reinterpret_cast<int*>(take(8));
+        if (pass == 0) {
+            const size_t need = off + 4096;
+            if (w.ibytes < need) {
+                if (w.imem) { VG_HIP(hipFree(w.imem)); w.imem = nullptr; w.ibytes = 0; }
+                VG_HIP(hipMalloc(&w.imem, need));
+                w.ibytes = need;
+            }
+            base = reinterpret_cast<char*>(w.imem);
+        }
+    }
+    it.nbc = nbc; it.maxit = maxit;
+    (void)c;
+    return VGGP_OK;
+}
+
+// G = L^T-side product: block field F[i][c][j] = l_i^T V_c r_j for all columns (V block [m1][nbc][m2], L: m1 x n1, R: m2 x n2)
+static int vgi_field(const VgMasked& w, const VgIter& it, const double* L, const double* V, const double* R, double* F, hipStream_t st) {
+    const int m1 = w.m1, m2 = w.m2, nbc = it.nbc;
+    const long n1 = w.n1, n2 = w.n2;
+    int rc;
+    // T1[i][(c,b)] = sum_a L[a][i] V[a][(c,b)]
+    if ((rc = gemm1(L, 1, n1, V, (long)nbc * m2, 1, it.T1, nbc * m2, (int)n1, nbc * m2, m1, st))) return rc;
+    // F[(i,c)][j] = sum_b T1[(i,c)][b] R[b][j]
+    return gemm1(it.T1, m2, 1, R, n2, 1, F, (int)n2, (int)(n1 * nbc), (int)n2, m2, st);
+}
+// out[a][(c,b)] = sum_{i,j} L[a][i] F[i][c][j] R[b][j]
+static int vgi_back(const VgMasked& w, const VgIter& it, const double* L, const double* F, const double* R, double* out, hipStream_t st) {
+    const int m1 = w.m1, m2 = w.m2, nbc = it.nbc;
+    const long n1 = w.n1, n2 = w.n2;
+    int rc;
+    // T1[(i,c)][b] = sum_j F[(i,c)][j] R[b][j]
+    if ((rc = gemm1(F, n2, 1, R, 1, n2, it.T1, m2, (int)(n1 * nbc), m2, (int)n2, st))) return rc;
+    return gemm1(L, n1, 1, it.T1, (long)nbc * m2, 1, out, nbc * m2, m1, nbc * m2, (int)n1, st);
+}
+// out = Q1 ((Q1^T V Q2) o f(dP)) Q2^T for the whole block (Qt rows = eigenvectors); mode as vgi_scale_kernel; c_from: columns below are zeroed
+static int vgi_rot(vggp_ctx* c, const VgMasked& w, const VgIter& it, const double* V, double* out, int mode, int c_from, double p, hipStream_t st,
+                   double* rotated_out = nullptr) {
+    const int m1 = w.m1, m2 = w.m2, nbc = it.nbc;
+    const long nb = (long)m1 * nbc * m2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    int rc;
+    if ((rc = gemm1(d1.Qt, m1, 1, V, (long)nbc * m2, 1, it.Tm, nbc * m2, m1, nbc * m2, m1, st))) return rc;            // Q1^T V
+    if ((rc = gemm1(it.Tm, m2, 1, d2.Qt, 1, m2, it.Tm2, m2, m1 * nbc, m2, m2, st))) return rc;                      // (.) Q2
+    if (rotated_out) VG_HIP(hipMemcpyAsync(rotated_out, it.Tm2, sizeof(double) * nb, hipMemcpyDeviceToDevice, st));
+    VGM_LAUNCH1D(vgi_scale_kernel, nb, st, it.Tm2, it.Tm2, d1.lam0, d2.lam0, c->theta, p, m1, nbc, m2, mode, c_from);
+    if ((rc = gemm1(it.Tm2, m2, 1, d2.Qt, m2, 1, it.Tm, m2, m1 * nbc, m2, m2, st))) return rc;                      // (.) Q2^T
+    return gemm1(d1.Qt, 1, m1, it.Tm, (long)nbc * m2, 1, out, nbc * m2, m1, nbc * m2, m1, st);                     // Q1 (.)
+}
+
+extern "C" int vggp_elbo_step_masked_iter(vggp_ctx* c, const double* Ym, const double* W, double n_obs, double yy_obs, const double theta[5],
+                                          int n_probes, double tol, int max_iter, double* elbo_out, double grad_out[5], vggp_info* info,
+                                          void* stream) {
+    if (!c || !c->planned) { vg_set_error("vggp_elbo_step_masked_iter: context not planned"); return VGGP_ESTATE; }
+    VG_REQUIRE(Ym && W && theta && elbo_out && grad_out, "vggp_elbo_step_masked_iter: null argument");
+    c->have_masked = false;
+    VG_REQUIRE(!(c->desc.flags & VGGP_FLAG_SCATTERED), "vggp_elbo_step_masked_iter: the context was planned for scattered points");
+    VG_REQUIRE(!(c->n_ranks > 1 || c->comm || c->cb), "vggp_elbo_step_masked_iter: single-rank contexts only");
+    if (n_probes <= 0) n_probes = 16;
+    if (max_iter <= 0) max_iter = 100;
+    if (!(tol > 0.0)) tol = 1e-10;
+    VG_REQUIRE(n_probes <= 63 && max_iter <= VGI_MAXIT, "vggp_elbo_step_masked_iter: n_probes <= 63, max_iter <= %d", VGI_MAXIT);
+    const long m1 = c->desc.m1, m2 = c->desc.m2, n1 = c->desc.n1, n2 = c->desc.n2, M = m1 * m2;
+    const int nbc = n_probes + 1;
+    VG_REQUIRE(n1 * nbc * n2 < (1L << 31) * 4 && n1 * nbc < (1L << 31) && M * nbc < (1L << 31), "vggp_elbo_step_masked_iter: problem too large");
+    VG_ENTER_DEVICE(c->device);
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    for (int i = 0; i < 5; ++i) {
+        VG_REQUIRE(theta[i] > 0.0 && std::isfinite(theta[i]), "theta[%d]=%g must be positive and finite", i, theta[i]);
+        c->h_theta[i] = theta[i];
+    }
+    int rc = vgm_prepare(c, /*iter=*/true);
+    if (rc) return rc;
+    VgMasked& w = *reinterpret_cast<VgMasked*>(c->masked);
+    VgIter it;
+    if ((rc = vgi_prepare(c, w, it, nbc, max_iter))) return rc;
+    // factors, Cholesky, B|V, Mk, the projections C0, C1, C2 and the full-grid Gram matrices G1 (d1.GH), G2 (mpay)
+    if ((rc = vg_partials_enqueue(c, Ym, w.mpay, st))) return rc;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const double *B1 = d1.BV, *V1 = d1.BV + m1 * n1, *B2 = d2.BV, *V2 = d2.BV + m2 * n2;
+    double *C0 = w.mpay + 2 * m2 * m2, *C1 = C0 + M, *C2 = C1 + M;
+    if ((rc = vgm_colstats(c, w, W, st))) return rc;
+    hipLaunchKernelGGL(vgi_transpose_kernel, dim3((unsigned)((n1 + 31) / 32), (unsigned)((n2 + 31) / 32)), dim3(32, 8), 0, st, W, n1, n2, it.Wt);
+    // eigenbasis of the preconditioner: the full-grid path's cold eigensolver on G1, G2
+    {
+        VgEigJob ej[2];
+        const double* G[2] = {d1.GH, w.mpay};
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            ej[k] = VgEigJob{G[k], d.lam0, d.Qt, nullptr, d.gwork, d.rotlog, d.roundlog, d.counters, d.m, d.max_rounds,
+                             (long)vg_eigh_log_bytes(d.m), 0};
+            ej[k].perm = d.perm;
+            ej[k].err = d.status + 1;
+        }
+        VG_HIP(vg_eigh_launch(ej, 2, st));
+    }
+    const double p = n_obs / ((double)n1 * (double)n2);
+    const long nb = M * nbc;
+    // right-hand sides: column 0 = c0, columns 1.. = z = P^1/2 z0;  Wz = P^-1 z = P^-1/2 z0
+    VGM_LAUNCH1D(vgi_probe_kernel, nb, st, it.X, (int)m1, nbc, (int)m2, 0x5647475000000001ULL);
+    if ((rc = vgi_rot(c, w, it, it.X, it.R, 1, 1, p, st))) return rc;
+    if ((rc = vgi_rot(c, w, it, it.X, it.Wz, 2, 1, p, st))) return rc;
+    VGM_LAUNCH1D(vgi_col_kernel, M, st, it.R, C0, (int)m1, nbc, (int)m2, 0, 0);
+    VG_HIP(hipMemsetAsync(it.X, 0, sizeof(double) * nb, st));
+    // PCG
+    if ((rc = vgi_rot(c, w, it, it.R, it.Zp, 0, 0, p, st))) return rc;
+    VG_HIP(hipMemcpyAsync(it.Pd, it.Zp, sizeof(double) * nb, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(vgi_coldots_kernel, dim3(nbc), dim3(256), 0, st, it.R, it.Zp, it.R, it.R, (int)m1, nbc, (int)m2, it.col, it.col + 3 * nbc);
+    hipLaunchKernelGGL(vgi_pcg_scalars_kernel, dim3(1), dim3(64), 0, st, it.col, nbc, 0, 0, tol, it.alh, it.beh, it.nact);
+    int iters = 0, nact = nbc;
+    for (int k = 0; k < max_iter && nact > 0; ++k) {
+        // AP = Pd + rho B1 (Wt o (B1^T Pd B2)) B2^T
+        if ((rc = vgi_field(w, it, B1, it.Pd, B2, it.F0, st))) return rc;
+        VGM_LAUNCH1D(vgi_mask_kernel, n1 * nbc * n2, st, it.F0, it.Wt, n1, nbc, n2);
+        if ((rc = vgi_back(w, it, B1, it.F0, B2, it.AP, st))) return rc;
+        VGM_LAUNCH1D(vgi_axpy_rho_kernel, nb, st, it.Pd, it.AP, c->theta, nb, it.AP);
+        hipLaunchKernelGGL(vgi_coldots_kernel, dim3(nbc), dim3(256), 0, st, it.Pd, it.AP, (const double*)nullptr, (const double*)nullptr, (int)m1, nbc,
+                           (int)m2, it.col + nbc, (double*)nullptr);
+        hipLaunchKernelGGL(vgi_pcg_scalars_kernel, dim3(1), dim3(64), 0, st, it.col, nbc, 1, k, tol, it.alh, it.beh, it.nact);
+        VGM_LAUNCH1D(vgi_update_kernel, nb, st, it.X, it.R, it.Pd, it.AP, it.Zp, it.col, (int)m1, nbc, (int)m2, 1);
+        if ((rc = vgi_rot(c, w, it, it.R, it.Zp, 0, 0, p, st))) return rc;
+        hipLaunchKernelGGL(vgi_coldots_kernel, dim3(nbc), dim3(256), 0, st, it.R, it.Zp, it.R, it.R, (int)m1, nbc, (int)m2, it.col + 5 * nbc,
+                           it.col + 3 * nbc);
+        hipLaunchKernelGGL(vgi_pcg_scalars_kernel, dim3(1), dim3(64), 0, st, it.col, nbc, 2, k, tol, it.alh, it.beh, it.nact);
+        VGM_LAUNCH1D(vgi_update_kernel, nb, st, it.X, it.R, it.Pd, it.AP, it.Zp, it.col, (int)m1, nbc, (int)m2, 2);
+        VG_HIP(hipMemcpyAsync(&c->h_out->counters[0][0], it.nact, sizeof(int), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipStreamSynchronize(st));
+        nact = c->h_out->counters[0][0];
+        iters = k + 1;
+    }
+    if (nact > 0) { vg_set_error("vggp_elbo_step_masked_iter: PCG did not reach %.1e in %d iterations (%d columns left)", tol, max_iter, nact); return VGGP_ENOCONV; }
+    // log det: log|P| + the quadratures
+    VG_HIP(hipMemsetAsync(it.ts, 0, 64 * sizeof(double), st));
+    VG_HIP(hipMemsetAsync(w.cholstatus, 0, sizeof(int), st));
+    hipLaunchKernelGGL(vgi_dpsum_kernel, dim3(1), dim3(256), 0, st, d1.lam0, d2.lam0, c->theta, p, (int)m1, (int)m2, (const double*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr, 1, it.ts + 0);
+    hipLaunchKernelGGL(vgi_slq_kernel, dim3(1), dim3(64), 0, st, it.alh, it.beh, it.col, nbc, (double)M, it.ts + 32, w.cholstatus);
+    hipLaunchKernelGGL(vgi_sum_kernel, dim3(1), dim3(64), 0, st, it.ts + 32, n_probes, it.ts + 1, 0);
+    // a0 and the a0 terms of the gradient
+    VGM_LAUNCH1D(vgi_col_kernel, M, st, it.X, w.a0, (int)m1, nbc, (int)m2, 0, 1);
+    if ((rc = vgm_a0_terms(c, w, st))) return rc;
+    // dU = Sigma~^-1 z - P^-1 z (probe columns)
+    VGM_LAUNCH1D(vgi_sub_kernel, nb, st, it.X, it.Wz, nb, it.Zp);
+    double* dU = it.Zp;
+    // stochastic parts of the traces: fields of dU and of Wz with (B1,B2), (V1,B2), (B1,V2)
+    auto fsum = [&](const double* Fa, const double* Fb, double* out) {
+        hipLaunchKernelGGL(vgi_fieldsum_part_kernel, dim3(1024), dim3(256), 0, st, Fa, Fb, it.Wt, n1, nbc, n2, it.AP);      // (AP is free after the PCG)
+        hipLaunchKernelGGL(vgi_sum_kernel, dim3(1), dim3(64), 0, st, it.AP, 1024, out, 0);
+    };
+    if ((rc = vgi_field(w, it, B1, it.Wz, B2, it.F0, st))) return rc;              // F0 = Fw^BB
+    if ((rc = vgi_field(w, it, B1, dU, B2, it.F1, st))) return rc;                 // F1 = Fu^BB
+    fsum(it.F1, it.F0, it.ts + 3);
+    if ((rc = vgi_field(w, it, V1, dU, B2, it.F2, st))) return rc;                 // Fu^VB
+    fsum(it.F2, it.F0, it.ts + 6);                                                 // (u-w)^T Phi'_1^T w
+    if ((rc = vgi_field(w, it, B1, dU, V2, it.F2, st))) return rc;                 // Fu^BV
+    fsum(it.F2, it.F0, it.ts + 9);
+    if ((rc = vgi_field(w, it, V1, it.Wz, B2, it.F0, st))) return rc;              // Fw^VB
+    fsum(it.F1, it.F0, it.ts + 5);
+    if ((rc = vgi_field(w, it, B1, it.Wz, V2, it.F0, st))) return rc;              // Fw^BV
+    fsum(it.F1, it.F0, it.ts + 8);
+    // Mk terms: <dU, Mk1 Wz>, <dU, Wz Mk2^T>
+    if ((rc = gemm1(d1.Mk, m1, 1, it.Wz, (long)nbc * m2, 1, it.Tm, nbc * (int)m2, (int)m1, nbc * (int)m2, (int)m1, st))) return rc;
+    hipLaunchKernelGGL(vgi_coldots_kernel, dim3(nbc), dim3(256), 0, st, dU, it.Tm, (const double*)nullptr, (const double*)nullptr, (int)m1, nbc,
+                       (int)m2, it.ts + 32, (double*)nullptr);
+    hipLaunchKernelGGL(vgi_sum_kernel, dim3(1), dim3(64), 0, st, it.ts + 32, nbc, it.ts + 11, 1);
+    if ((rc = gemm1(it.Wz, m2, 1, d2.Mk, 1, m2, it.Tm, (int)m2, (int)(m1 * nbc), (int)m2, (int)m2, st))) return rc;
+    hipLaunchKernelGGL(vgi_coldots_kernel, dim3(nbc), dim3(256), 0, st, dU, it.Tm, (const double*)nullptr, (const double*)nullptr, (int)m1, nbc,
+                       (int)m2, it.ts + 32, (double*)nullptr);
+    hipLaunchKernelGGL(vgi_sum_kernel, dim3(1), dim3(64), 0, st, it.ts + 32, nbc, it.ts + 13, 1);
+    // exact parts: factors rotated into the eigenbasis of P
+    if ((rc = gemm1(d1.Qt, m1, 1, B1, n1, 1, it.Rr1, (int)n1, (int)m1, (int)n1, (int)m1, st))) return rc;
+    if ((rc = gemm1(d1.Qt, m1, 1, V1, n1, 1, it.Rv1, (int)n1, (int)m1, (int)n1, (int)m1, st))) return rc;
+    if ((rc = gemm1(d2.Qt, m2, 1, B2, n2, 1, it.Rr2, (int)n2, (int)m2, (int)n2, (int)m2, st))) return rc;
+    if ((rc = gemm1(d2.Qt, m2, 1, V2, n2, 1, it.Rv2, (int)n2, (int)m2, (int)n2, (int)m2, st))) return rc;
+    VGM_LAUNCH1D(vgi_mul_kernel, m1 * n1, st, it.Rr1, it.Rr1, m1 * n1, it.RR1);
+    VGM_LAUNCH1D(vgi_mul_kernel, m1 * n1, st, it.Rr1, it.Rv1, m1 * n1, it.RRV1);
+    VGM_LAUNCH1D(vgi_mul_kernel, m2 * n2, st, it.Rr2, it.Rr2, m2 * n2, it.RR2);
+    VGM_LAUNCH1D(vgi_mul_kernel, m2 * n2, st, it.Rr2, it.Rv2, m2 * n2, it.RRV2);
+    if ((rc = gemm1(it.Wt, n2, 1, it.RR2, 1, n2, it.TW, (int)m2, (int)n1, (int)m2, (int)n2, st))) return rc;        // Wt RR2^T  (n1 x m2)
+    if ((rc = gemm1(it.Wt, n2, 1, it.RRV2, 1, n2, it.TWv, (int)m2, (int)n1, (int)m2, (int)n2, st))) return rc;
+    auto exact = [&](const double* RRa, const double* TWb, double* out) -> int {
+        int r2 = gemm_longk(RRa, n1, 1, TWb, m2, 1, it.Ex, (int)m1, (int)m2, (int)n1, w.T, st);
+        if (r2) return r2;
+        hipLaunchKernelGGL(vgi_dpsum_kernel, dim3(1), dim3(256), 0, st, d1.lam0, d2.lam0, c->theta, p, (int)m1, (int)m2, it.Ex,
+                           (const double*)nullptr, (const double*)nullptr, 0, out);
+        return VGGP_OK;
+    };
+    if ((rc = exact(it.RR1, it.TW, it.ts + 2))) return rc;
+    if ((rc = exact(it.RRV1, it.TW, it.ts + 4))) return rc;
+    if ((rc = exact(it.RR1, it.TWv, it.ts + 7))) return rc;
+    // tr(P^-1 (Mk1 (x) I)) = sum_ab diag(Q1^T Mk1 Q1)_a / dP_ab, likewise dimension 2
+    if ((rc = gemm1(d1.Qt, m1, 1, d1.Mk, m1, 1, it.Tq, (int)m1, (int)m1, (int)m1, (int)m1, st))) return rc;
+    VGM_LAUNCH1D(vgi_rowdot_kernel, m1, st, it.Tq, d1.Qt, (int)m1, it.dg1);
+    if ((rc = gemm1(d2.Qt, m2, 1, d2.Mk, m2, 1, it.Tq, (int)m2, (int)m2, (int)m2, (int)m2, st))) return rc;
+    VGM_LAUNCH1D(vgi_rowdot_kernel, m2, st, it.Tq, d2.Qt, (int)m2, it.dg2);
+    hipLaunchKernelGGL(vgi_dpsum_kernel, dim3(1), dim3(256), 0, st, d1.lam0, d2.lam0, c->theta, p, (int)m1, (int)m2, (const double*)nullptr, it.dg1,
+                       (const double*)nullptr, 0, it.ts + 10);
+    hipLaunchKernelGGL(vgi_dpsum_kernel, dim3(1), dim3(256), 0, st, d1.lam0, d2.lam0, c->theta, p, (int)m1, (int)m2, (const double*)nullptr,
+                       (const double*)nullptr, it.dg2, 0, it.ts + 12);
+    // the dense step's reductions that do not involve Sigma~^-1 as a matrix; the six that do come from the combine kernel
+    VgmRedArgs ra;
+    ra.njobs = RJ_COUNT;
+    ra.partial = w.partial;
+    auto job = [&](int k, const double* a, const double* b, long n, long sa, long sb, int op, const double* cc = nullptr) {
+        ra.job[k] = VgmRedJob{a, b, cc, n, sa, sb, op};
+    };
+    for (int k = 0; k < RJ_COUNT; ++k) job(k, w.a0, w.a0, 0, 1, 1, 0);
+    job(RJ_Q, C0, w.a0, M, 1, 1, 0);
+    job(RJ_AA, w.a0, w.a0, M, 1, 1, 0);
+    job(RJ_TRPHI, w.nb1, w.wn2, n1, 1, 1, 0);
+    job(RJ_TRMK1, d1.Mk, nullptr, m1, m1 + 1, 0, 2);
+    job(RJ_AC1, w.a0, C1, M, 1, 1, 0);
+    job(RJ_MKA1, w.MkA1, w.a0, M, 1, 1, 0);
+    job(RJ_Z1, W, w.Zb, n1 * n2, 1, 1, 3, w.Zv1);
+    job(RJ_HV1, w.hv1, w.wn2, n1, 1, 1, 0);
+    job(RJ_MK1PT, d1.Mk, w.PT1, m1 * m1, 1, 1, 0);
+    job(RJ_TRMK2, d2.Mk, nullptr, m2, m2 + 1, 0, 2);
+    job(RJ_AC2, w.a0, C2, M, 1, 1, 0);
+    job(RJ_MKA2, w.MkA2, w.a0, M, 1, 1, 0);
+    job(RJ_Z2, W, w.Zb, n1 * n2, 1, 1, 3, w.Zv2);
+    job(RJ_HV2, w.hv2, w.wn1, n2, 1, 1, 0);
+    job(RJ_MK2PT, d2.Mk, w.PT2, m2 * m2, 1, 1, 0);
+    hipLaunchKernelGGL(vgm_red_kernel, dim3(VG_MD_NPART, RJ_COUNT), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(vgm_sum_kernel, dim3(1), dim3(64), 0, st, w.partial, w.scal, 0u, 1);
+    hipLaunchKernelGGL(vgi_combine_kernel, dim3(1), dim3(64), 0, st, it.ts, c->theta, (double)M, n_probes, w.scal);
+    VgmFinalArgs fa{c->theta, w.scal, w.out, n_obs, yy_obs, (int)m1, (int)m2};
+    hipLaunchKernelGGL(vgm_final_kernel, dim3(1), dim3(64), 0, st, fa);
+    VG_HIP(hipGetLastError());
+    VG_HIP(hipMemcpyAsync(c->h_out->out, w.out, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < 2; ++k) {
+        VG_HIP(hipMemcpyAsync(&c->h_out->jitter[k], c->d[k].jitter, sizeof(double), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipMemcpyAsync(&c->h_out->status[k], c->d[k].status, sizeof(int), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipMemcpyAsync(&c->h_out->counters[k][2], c->d[k].counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    VG_HIP(hipMemcpyAsync(&c->h_out->counters[1][3], w.cholstatus, sizeof(int), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    *elbo_out = c->h_out->out[0];
+    for (int i = 0; i < 5; ++i) grad_out[i] = c->h_out->out[1 + i];
+    int status = c->h_out->status[0] ? c->h_out->status[0] : (c->h_out->status[1] ? c->h_out->status[1] : 0);
+    if (!status) status = c->h_out->counters[0][2] ? c->h_out->counters[0][2] : c->h_out->counters[1][2];
+    if (info) {
+        info->jitter1 = c->h_out->jitter[0]; info->jitter2 = c->h_out->jitter[1];
+        info->sweeps1 = n_probes; info->sweeps2 = 0; info->rounds1 = iters; info->rounds2 = 0;
+        info->status = status; info->polished = 0;
+    }
+    if (status == VGGP_ENOTPD) { vg_set_error("iterative masked step: a factor is not positive definite"); return VGGP_ENOTPD; }
+    if (status) { vg_set_error("iterative masked step: the preconditioner's eigensolver failed (status %d)", status); return VGGP_ENOCONV; }
+    if (c->h_out->counters[1][3]) { vg_set_error("iterative masked step: the Lanczos quadrature failed (code %d)", c->h_out->counters[1][3]); return VGGP_ENOCONV; }
+    c->have_step = false; c->have_partials = false;
     return VGGP_OK;
 }

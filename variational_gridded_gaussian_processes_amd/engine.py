@@ -181,6 +181,20 @@ class Engine:
                                              grad, C.byref(info), _stream(self.device)))
         return elbo.value, np.array(list(grad)), self._info(info)
 
+    def elbo_step_masked_iter(self, Ym: torch.Tensor, W: torch.Tensor, n_obs: float, yy_obs: float, theta: Sequence[float],
+                              n_probes: int = 16, tol: float = 1e-10, max_iter: int = 100):
+        """The masked step without any M x M matrix (PCG + Lanczos quadrature + control-variate trace estimators, fixed probes;
+        include/vggp.h): -> (elbo, grad[5], info) with info['rounds'][0] = PCG iterations."""
+        self._check_Y(Ym)
+        self._check_Y(W)
+        th = (C.c_double * 5)(*[float(t) for t in theta])
+        elbo = C.c_double()
+        grad = (C.c_double * 5)()
+        info = Info()
+        check(self.lib.vggp_elbo_step_masked_iter(self._h, _ptr(Ym), _ptr(W), float(n_obs), float(yy_obs), th, int(n_probes), float(tol),
+                                                  int(max_iter), C.byref(elbo), grad, C.byref(info), _stream(self.device)))
+        return elbo.value, np.array(list(grad)), self._info(info)
+
     def elbo_step_scattered(self, y: torch.Tensor, yy: float, theta: Sequence[float]):
         """N scattered points (plan(..., scattered=True) with their coordinate pairs): y [N] float64 GPU tensor, yy = sum y^2;
         -> (elbo, grad[5], info).  qv_masked / posterior_masked / the *_cov_masked read-outs apply afterwards."""
