@@ -27,6 +27,7 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 
 #include "ctx.h"
 #include "factor_elem.h"
+#define VG_CHOL_MAXJOBS_HOST 8
 
 static void graphs_clear(vggp_ctx* c);
 static int vg_quiesce(vggp_ctx* c);
@@ -239,6 +240,10 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.L0 = b.take<double>(m * m);
         d.Linv0 = b.take<double>(m * m);
         d.Dinv0 = b.take<double>(((m + 15) / 16) * 256);
+        if (m > 128) {                   // blocked Cholesky of the step (vg_chol_big_enqueue)
+            d.Kc = b.take<double>(4 * m * m); d.Lc = b.take<double>(4 * m * m); d.Dc = b.take<double>(4 * ((m + 15) / 16) * 256);
+            d.st8 = b.take<int>(8);
+        }
         d.X = b.take<double>(m * m);
         d.chol_scratch = b.take<double>(m * (m + 1));
         d.RQ = b.take<double>(m * m);
@@ -259,7 +264,7 @@ static void layout(vggp_ctx* c, Bump& b) {
         d.max_rounds = (int)(VG_EIG_MAXSWEEP * (m2e - 1));
         d.rotlog = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
         d.roundlog = b.take<int>(d.max_rounds);
-        if (m >= 24 && m <= 128) {       // subspace start: the small problem has at most m/2 rows
+        if (m >= 24 && m <= 256) {       // subspace start: the small problem has at most m/2 rows (m > 128: the thin chain only)
             d.gwork2 = b.take<double>(m2e * (m2e + 1));
             d.rotlog2 = b.take<double2>(vg_eigh_log_bytes((int)m) / sizeof(double2) + 1);
             d.roundlog2 = b.take<int>(d.max_rounds);
@@ -435,6 +440,63 @@ static bool vg_ride(const vggp_ctx* c) {
     return !off && !c->prof && c->desc.m1 <= 128 && c->desc.m2 <= 128;
 }
 
+// Cholesky of a factor with 128 < m <= 256 inside the step: [[A11, .], [A21, A22]] with a 128-block A11, all four jitter levels
+// side by side as independent plain factorisations of K + jitter I (the step's graph cannot walk the jitter ladder on the host):
+// per level  L11 = chol(A11), L21 = A21 L11^-T (substitution), S22 = A22 - L21 L21^T (MFMA), L22 = chol(S22); the lowest level
+// whose two blocks both survive is selected on the device.  Leaves L0, the inverses of its 16 x 16 diagonal blocks (Dinv0), the
+// jitter value and the status word -- exactly what the m <= 128 launch leaves.  (The single-workgroup generic kernel this replaces
+// took 3.0 ms at m = 256: profiles/r2_md256_kernel_stats.csv.)
+static int vg_chol_big_enqueue(vggp_ctx* c, const int* dims, int ndims, hipStream_t st) {
+    VgCholJob cj[VG_CHOL_MAXJOBS_HOST];
+    int nj = 0;
+    for (int t = 0; t < ndims; ++t) {
+        VgDim& d = c->d[dims[t]];
+        VG_HIP(vg_jitcopy_launch(d.K0, d.m, d.Kc, st));
+    }
+    const long NB = 128;
+    for (int stage = 0; stage < 2; ++stage) {
+        if (stage == 1) {
+            // L21^T = L11^-1 A21^T by substitution (transposed views), then S22 = A22 + jitter I - L21 L21^T in place
+            VgTrsmJob tj[8];
+            int nt = 0;
+            VgGemmBatch g;
+            vg_gemm_init(&g);
+            for (int t = 0; t < ndims; ++t) {
+                VgDim& d = c->d[dims[t]];
+                const long m = d.m, mm = m * m, rest = m - NB, nb16 = (m + 15) / 16;
+                for (int l = 0; l < 4; ++l) {
+                    double* Kl = d.Kc + l * mm;
+                    double* Ll = d.Lc + l * mm;
+                    // R(k, c) = A21[c][k], X(k, c) -> L21[c][k]: both with element (k, c) at base[k + c * m]
+                    tj[nt++] = VgTrsmJob{Ll, d.Dc + l * nb16 * 256, Kl + NB * m, Ll + NB * m, m, 256, 16, 1, m, 1, m, rest, (int)NB, 0};
+                    vg_gemm_add(&g, Ll + NB * m, m, 1, Ll + NB * m, 1, m, Kl + NB * m + NB, (int)m, (int)rest, (int)rest, (int)NB, 1, 0, 1, 0, -1.0, 1);
+                }
+            }
+            VG_HIP(vg_trsm_launch(tj, nt, st));
+            VG_HIP(vg_gemm_launch(&g, st));
+        }
+        nj = 0;
+        for (int t = 0; t < ndims; ++t) {
+            VgDim& d = c->d[dims[t]];
+            const long m = d.m, mm = m * m, nb16 = (m + 15) / 16;
+            const long o = stage ? NB : 0;
+            const int mb = stage ? (int)(m - NB) : (int)NB;
+            for (int l = 0; l < 4; ++l) {
+                VgCholJob j{d.Kc + l * mm + o * m + o, d.Lc + l * mm + o * m + o, nullptr, d.chol_scratch, nullptr, d.st8 + 2 * l + stage, mb};
+                j.ldk = (int)m; j.ldl = (int)m; j.only_level0 = 1;
+                j.Dinv_out = d.Dc + l * nb16 * 256 + (o / 16) * 256;
+                cj[nj++] = j;
+            }
+        }
+        VG_HIP(vg_chol_launch(cj, nj, st));
+    }
+    for (int t = 0; t < ndims; ++t) {
+        VgDim& d = c->d[dims[t]];
+        VG_HIP(vg_cholsel_launch(d.Lc, d.Dc, d.st8, d.m, d.L0, d.Dinv0, d.jitter, d.status, st));
+    }
+    return VGGP_OK;
+}
+
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap, bool fused, bool apply_ns) {
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
@@ -460,6 +522,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         clr.ptr[clr.n] = reinterpret_cast<int*>(d.chol_scratch); clr.nwords[clr.n++] = 16;     // jitter-level flags
         clr.ptr[clr.n] = d.counters; clr.nwords[clr.n++] = 8;                                  // Jacobi progress words (counters, counters2)
         if (k == 0) { clr.ptr[clr.n] = reinterpret_cast<int*>(c->payload + c->payload_len); clr.nwords[clr.n++] = 2; }   // peer-failure word
+        if (d.st8) { clr.ptr[clr.n] = d.st8; clr.nwords[clr.n++] = 8; }                        // block statuses of the m > 128 Cholesky
         cj[k] = VgCholJob{d.K0, d.L0, dinv_path ? nullptr : d.Linv0, d.chol_scratch, d.jitter, d.status, d.m};
         cj[k].Dinv_out = d.Dinv0;
     }
@@ -478,8 +541,22 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
             VgDim& d = c->d[k];
             vg_gemm_add(&gns, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
         }
-    VG_HIP(vg_chol_launch(cj, 2, st, ns_on_chol ? &gns : nullptr));
-    c->dinv_valid = dinv_path;
+    static const bool chol_big_off = getenv("VGGP_NO_CHOL_BIG") != nullptr;
+    const bool any_big = (d1.m > VG_TRSM_BLK || d2.m > VG_TRSM_BLK) && !chol_legacy && !chol_big_off;
+    if (!any_big) {
+        VG_HIP(vg_chol_launch(cj, 2, st, ns_on_chol ? &gns : nullptr));
+    } else {
+        // a factor beyond one 128-block: blocked (vg_chol_big_enqueue); a small partner keeps the one-launch MFMA kernel.  Either
+        // way the launch leaves L0 and the diagonal-block inverses only; L0^-1 comes out of the substitution below.
+        int big[2], nbig = 0;
+        for (int k = 0; k < 2; ++k) {
+            if (c->d[k].m > VG_TRSM_BLK) big[nbig++] = k;
+            else { cj[k].Linv = nullptr; VG_HIP(vg_chol_launch(&cj[k], 1, st)); }
+        }
+        const int rcb = vg_chol_big_enqueue(c, big, nbig, st);
+        if (rcb) return rcb;
+    }
+    c->dinv_valid = dinv_path || any_big;
     VG_MARK(1);
 
     // 3. B|V = L0^{-1} [A0|dA0],  X = L0^{-1} dK0  by blocked substitution on the matrix cores (trsm.hip; the 16 x 16
@@ -506,15 +583,22 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
             VG_HIP(vg_trsm_launch(tj, nt, st));
         } else {
             // 128 < m <= 256: blocked (128-row diagonal solves + one GEMM update between them), in place on copies
-            VgTrsmSpec q[6];
+            VgTrsmSpec q[8];
             int nq = 0;
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
                 const long mn = (long)d.m * d.n;
+                // diagonal-block inverses: Dinv0 when the Cholesky left them there, else the diagonal blocks of its explicit inverse
+                const double* dv = any_big ? d.Dinv0 : d.Linv0;
+                const long dblk = any_big ? 256 : 16L * d.m + 16, dld = any_big ? 16 : d.m;
                 VG_HIP(hipMemcpyAsync(d.BV, d.AD, sizeof(double) * 2 * mn, hipMemcpyDeviceToDevice, st));
                 VG_HIP(hipMemcpyAsync(d.X, d.dK0, sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
-                for (int b = 0; b < 2; ++b) q[nq++] = VgTrsmSpec{d.L0, d.m, d.Linv0, 16L * d.m + 16, d.m, d.BV + b * mn, d.n, 1, d.n, d.m, 0};
-                q[nq++] = VgTrsmSpec{d.L0, d.m, d.Linv0, 16L * d.m + 16, d.m, d.X, d.m, 1, d.m, d.m, 0};
+                for (int b = 0; b < 2; ++b) q[nq++] = VgTrsmSpec{d.L0, d.m, dv, dblk, dld, d.BV + b * mn, d.n, 1, d.n, d.m, 0};
+                q[nq++] = VgTrsmSpec{d.L0, d.m, dv, dblk, dld, d.X, d.m, 1, d.m, d.m, 0};
+                if (any_big) {           // L0^-1 = L0^-1 I, as in the m <= 128 launch
+                    VG_HIP(hipMemcpyAsync(d.Linv0, d.Id, sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
+                    q[nq++] = VgTrsmSpec{d.L0, d.m, dv, dblk, dld, d.Linv0, d.m, 1, d.m, d.m, 0};
+                }
             }
             const int rc = trsm_batch(q, nq, st);
             if (rc) return rc;
@@ -1082,7 +1166,9 @@ static bool vg_warm(vggp_ctx* c, bool own_payload) {
 static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out, bool own_payload) {
     out->thin = warm && vg_thin_ok(c, own_payload);
     out->extrap = !out->thin && vg_extrapolate(c);
-    out->subspace = out->thin || (warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0);
+    // (the full subspace chain -- complement basis, sparse-first main solve -- lives in the LDS eigensolver body: m <= 128)
+    const bool lds_sized = c->d[0].m <= 128 && c->d[1].m <= 128;
+    out->subspace = out->thin || (lds_sized && warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0);
     out->refine = warm && !out->subspace && vg_refine(c, out->extrap);
     c->sub_mode = out->subspace;
     if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
@@ -1209,6 +1295,7 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
                 if (want > d.m - 8) want = d.m - 8;
                 if (want < 8 || want > 48) want = 0;
             }
+            if (d.m > 128 && want > VG_THIN_MAXR) want = 0;      // beyond one LDS-resident matrix only the thin chain exists
             if (want == 0) d.sub_r = 0;
             else if (want > d.sub_r || want < d.sub_r - 8) d.sub_r = want;
             ok = ok && d.sub_r > 0;

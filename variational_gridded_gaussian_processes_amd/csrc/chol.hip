@@ -25,10 +25,11 @@
 static const int VG_CHOL_FAST_MAX_M = 128;      // fast paths: matrix resident in the LDS of one CU
 __constant__ double VG_JITTERS[4] = {0.0, 1e-8, 1e-7, 1e-6};
 
+#define VG_CHOL_MAXJOBS 8
 struct VgCholArgs {
-    VgCholJob job[4];
+    VgCholJob job[VG_CHOL_MAXJOBS];
     int njobs;
-    int fast[4];
+    int fast[VG_CHOL_MAXJOBS];
 };
 
 __device__ __forceinline__ int vg_ctri(int i) { return (i * (i + 1)) >> 1; }
@@ -626,6 +627,51 @@ __global__ __launch_bounds__(1024) void vg_chol_kernel(const VgCholArgs a) {
 }
 
 
+// ---- 128 < m <= 256: two 128-blocks, all four jitter levels side by side (api.hip vg_chol_big_enqueue) ---------------------------
+// Kc[lvl] = K + jitter_lvl I  (four full copies: the levels are then plain only_level0 jobs whose status words say which survived)
+__global__ void vg_jitcopy_kernel(const double* K, int m, double* Kc) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long)m * m;
+    if (idx >= 4 * mm) return;
+    const int lvl = (int)(idx / mm);
+    const long e = idx - lvl * mm;
+    Kc[idx] = K[e] + ((e / m == e % m) ? VG_JITTERS[lvl] : 0.0);
+}
+hipError_t vg_jitcopy_launch(const double* K, int m, double* Kc, hipStream_t st) {
+    hipLaunchKernelGGL(vg_jitcopy_kernel, dim3((unsigned)((4L * m * m + 255) / 256)), dim3(256), 0, st, K, m, Kc);
+    return hipGetLastError();
+}
+// The lowest level whose two block factorisations both succeeded wins: its factor (upper triangle zeroed), the inverses of its
+// 16 x 16 diagonal blocks, the jitter value; VGGP_ENOTPD when none did.  st8: [lvl][stage] status words of the 8 block jobs.
+__global__ void vg_cholsel_kernel(const double* Lc, const double* Dc, const int* st8, int m, int nb16, double* L0, double* Dinv0,
+                                  double* jitter_out, int* status) {
+    __shared__ int s_lvl;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {}
+    if (threadIdx.x == 0) {
+        int lvl = -1;
+        for (int l = 3; l >= 0; --l) if (st8[2 * l] == 0 && st8[2 * l + 1] == 0) lvl = l;
+        s_lvl = lvl;
+    }
+    __syncthreads();
+    const int lvl = s_lvl;
+    const long mm = (long)m * m;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (lvl < 0) { *status = VGGP_ENOTPD; *jitter_out = -1.0; }
+        else *jitter_out = VG_JITTERS[lvl];
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < mm; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / m), j = (int)(e - (long)i * m);
+        L0[e] = lvl < 0 ? qnan : (j <= i ? Lc[lvl * mm + e] : 0.0);
+    }
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)nb16 * 256; e += (long)gridDim.x * blockDim.x)
+        Dinv0[e] = lvl < 0 ? qnan : Dc[(long)lvl * nb16 * 256 + e];
+}
+hipError_t vg_cholsel_launch(const double* Lc, const double* Dc, const int* st8, int m, double* L0, double* Dinv0, double* jitter_out,
+                             int* status, hipStream_t st) {
+    hipLaunchKernelGGL(vg_cholsel_kernel, dim3(64), dim3(256), 0, st, Lc, Dc, st8, m, (m + 15) / 16, L0, Dinv0, jitter_out, status);
+    return hipGetLastError();
+}
+
 hipError_t vg_chol_setup() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_chol_mfma_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -635,7 +681,7 @@ hipError_t vg_chol_setup() {
 }
 
 hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider) {
-    if (njobs < 1 || njobs > 4) return hipErrorInvalidValue;
+    if (njobs < 1 || njobs > VG_CHOL_MAXJOBS) return hipErrorInvalidValue;
     VgCholArgs a;
     a.njobs = njobs;
     size_t lds = 0;

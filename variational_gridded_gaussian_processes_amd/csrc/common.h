@@ -142,6 +142,10 @@ struct VgCholJob {
 struct VgGemmBatch;
 hipError_t vg_chol_launch(const VgCholJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);   // rider: m <= 128 path only
 hipError_t vg_chol_setup();   // opt-in to large dynamic LDS
+// 128 < m <= 256 (api.hip vg_chol_big_enqueue): four jittered copies of K; selection of the lowest level that survived both blocks
+hipError_t vg_jitcopy_launch(const double* K, int m, double* Kc, hipStream_t st);
+hipError_t vg_cholsel_launch(const double* Lc, const double* Dc, const int* st8, int m, double* L0, double* Dinv0, double* jitter_out,
+                             int* status, hipStream_t st);
 
 // ---- triangular solves by substitution (trsm.hip) -------------------------------------------------------------------
 struct VgTrsmJob {
@@ -290,7 +294,7 @@ hipError_t vg_zdot_launch(const double* theta, int self, const double* z, const 
 
 // zero a handful of small device buffers with ONE kernel (used instead of hipMemsetAsync: memset nodes of a
 // captured graph were observed to replay with a wrong fill value after an unrelated hipMalloc on ROCm 7.2)
-#define VG_CLEAR_MAX 8
+#define VG_CLEAR_MAX 12
 struct VgClearArgs { int* ptr[VG_CLEAR_MAX]; int nwords[VG_CLEAR_MAX]; int n; };
 hipError_t vg_clear_launch(const VgClearArgs* a, hipStream_t st);
 

@@ -9,6 +9,8 @@ struct VgDim {
     int kind = 0, basis = 0, n = 0, m = 0;
     double *x = nullptr, *grid = nullptr;
     double *K0 = nullptr, *dK0 = nullptr, *AD = nullptr, *L0 = nullptr, *Linv0 = nullptr, *BV = nullptr;
+    double *Kc = nullptr, *Lc = nullptr, *Dc = nullptr;   // 128 < m <= 256: four jittered copies of K0, their factors, their diagonal-block inverses
+    int* st8 = nullptr;               // ... and the status words [level][block] of the eight block factorisations
     double* Dinv0 = nullptr;          // [ceil(m/16)][16][16]: inverses of the diagonal blocks of L0 (left by the Cholesky launch)
     double *X = nullptr, *Mk = nullptr, *GH = nullptr, *GHslab = nullptr, *Gw = nullptr;
     double *lam0 = nullptr, *Qt = nullptr, *QtPrev = nullptr, *QtPrev2 = nullptr, *U = nullptr;

@@ -1619,16 +1619,10 @@ size_t vg_eigh_log_bytes(int m) {
 // Classical Gram-Schmidt with re-orthogonalisation, row by row, everything in LDS: the k dot products of a row are taken
 // by the 16 waves in parallel, then 128 lanes subtract; a third pass when a pass removed most of the row.
 struct VgRowQrArgs { VgRowQrJob job[2]; int njobs; };
-__global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, const VgGemmBatch rider) {
-    extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
-    if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
-        if (threadIdx.x >= 512) return;
-        vg_gemm_body<64, 16, 512>(rider, vq_dyn, blockIdx.x - a.njobs);
-        return;
-    }
-    const VgRowQrJob& J = a.job[blockIdx.x];
+// NE: elements of a row per lane in the in-block pass of wave 0 (2: m <= 128, 4: m <= 256)
+template <int NE>
+__device__ __forceinline__ void vg_rowqr_body(const VgRowQrJob& J, double* V) {
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* V = vq_dyn;                 // [r][m]: rows < k are finished, row k is in work, rows > k still hold Z (one load)
     // the pass-through copy: loads now (registers), stores after the last row -- a global store inside the row loop would be
     // waited for at every barrier (__syncthreads drains vmcnt)
     double cpv[16];
@@ -1637,8 +1631,8 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
     for (int i = tid; i < r * m; i += 1024) V[i] = J.Z[i];
     __syncthreads();
     // Block Gram-Schmidt, 4 rows at a time (r is a multiple of 4): the block is projected off all finished rows twice
-    // (4 k0 dot products per pass, 16 lanes each, one barrier; 512 threads subtract), then wave 0 alone orthonormalises the
-    // four rows among themselves in registers (two elements per lane, wave reductions, no workgroup barrier).
+    // (4 k0 dot products per pass, 16 lanes each, one barrier; 4 x EW threads subtract), then wave 0 alone orthonormalises the
+    // four rows among themselves in registers (NE elements per lane, wave reductions, no workgroup barrier).
     // "Twice is enough", but only where it is needed (Kahan / Parlett): a projection is repeated when it removed more than
     // half of a row's squared norm -- the trailing rows of Z, which are dominated by what leaks onto the leading eigenvectors;
     // the leading rows of a warm start lose almost nothing and take one pass.  The norms come for free: |x|^2 rides in the same
@@ -1646,6 +1640,7 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
     __shared__ double cb[4 * 64];
     __shared__ double nb2[4];
     __shared__ int need2[4];
+    constexpr int EW = 64 * NE;                              // threads per row in the subtraction
     const int grp = tid >> 4, l16 = lane & 15;               // 64 groups of 16 lanes
     for (int k0 = 0; k0 < r; k0 += 4) {
         double* vb = V + k0 * m;
@@ -1659,8 +1654,8 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
                 if (l16 == 0) { if (j < k0) cb[bb * 64 + j] = s; else nb2[bb] = s; }
             }
             __syncthreads();
-            if (tid < 512) {
-                const int e = tid & 127, bb = tid >> 7;
+            if (tid < 4 * EW) {
+                const int e = tid & (EW - 1), bb = tid / EW;
                 if (e < m) {
                     const double* cc = cb + bb * 64;
                     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
@@ -1674,8 +1669,9 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
                     for (; j < k0; ++j) x0 += cc[j] * V[j * m + e];
                     vb[bb * m + e] -= (x0 + x1) + (x2 + x3);
                 }
-            } else if (pass == 0 && tid >= 512 && tid < 516) {          // one lane per row decides about the second pass
-                const int bb = tid - 512;
+            }
+            if (pass == 0 && tid >= 1020) {                                  // one lane per row decides about the second pass
+                const int bb = tid - 1020;
                 const double* cc = cb + bb * 64;
                 double sc2 = 0.0;
                 for (int j = 0; j < k0; ++j) sc2 += cc[j] * cc[j];
@@ -1685,12 +1681,11 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
             if (pass == 0 && !(need2[0] | need2[1] | need2[2] | need2[3])) break;      // uniform
         }
         if (wave == 0) {
-            double x[4][2];
+            double x[4][NE];
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                x[bb][0] = lane < m ? vb[bb * m + lane] : 0.0;
-                x[bb][1] = lane + 64 < m ? vb[bb * m + lane + 64] : 0.0;
-            }
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int u = 0; u < NE; ++u) x[bb][u] = lane + 64 * u < m ? vb[bb * m + lane + 64 * u] : 0.0;
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 double n2 = 0.0;
@@ -1699,8 +1694,11 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
                     // independent reductions through one butterfly
                     double c[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int jb = 0; jb < bb; ++jb) c[jb] = x[bb][0] * x[jb][0] + x[bb][1] * x[jb][1];
-                    c[3] = x[bb][0] * x[bb][0] + x[bb][1] * x[bb][1];
+                    for (int jb = 0; jb < bb; ++jb)
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) c[jb] += x[bb][u] * x[jb][u];
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) c[3] += x[bb][u] * x[bb][u];
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -1710,21 +1708,22 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
                     double sc2 = 0.0;
 #pragma unroll
                     for (int jb = 0; jb < bb; ++jb) {
-                        x[bb][0] -= c[jb] * x[jb][0];
-                        x[bb][1] -= c[jb] * x[jb][1];
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) x[bb][u] -= c[jb] * x[jb][u];
                         sc2 += c[jb] * c[jb];
                     }
                     n2 = c[3] - sc2;                                         // |x|^2 after the projection
                     if (n2 >= 0.5 * c[3]) break;                             // wave-uniform: little was removed, once is enough
                 }
                 const double sc = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
-                x[bb][0] *= sc; x[bb][1] *= sc;
+#pragma unroll
+                for (int u = 0; u < NE; ++u) x[bb][u] *= sc;
             }
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                if (lane < m) vb[bb * m + lane] = x[bb][0];
-                if (lane + 64 < m) vb[bb * m + lane + 64] = x[bb][1];
-            }
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int u = 0; u < NE; ++u)
+                    if (lane + 64 * u < m) vb[bb * m + lane + 64 * u] = x[bb][u];
         }
         __syncthreads();
     }
@@ -1732,6 +1731,17 @@ __global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, con
 #pragma unroll
     for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; if (i < J.cp_n) J.cp_dst[i] = cpv[u]; }
     for (long i = tid + 16 * 1024L; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];      // (m <= 128: never taken)
+}
+__global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, const VgGemmBatch rider) {
+    extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
+    if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
+        if (threadIdx.x >= 512) return;
+        vg_gemm_body<64, 16, 512>(rider, vq_dyn, blockIdx.x - a.njobs);
+        return;
+    }
+    const VgRowQrJob& J = a.job[blockIdx.x];
+    if (J.m <= 128) vg_rowqr_body<2>(J, vq_dyn);
+    else vg_rowqr_body<4>(J, vq_dyn);
 }
 
 static const size_t VG_RIDER_LDS = 2 * VgTile<64, 16>::TILE * sizeof(double);
@@ -1746,7 +1756,7 @@ hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st, co
     if (rider && rider->nprob > 0 && rider->total_tiles > 0) { rb = *rider; lds = VG_RIDER_LDS; }
     for (int j = 0; j < njobs; ++j) {
         a.job[j] = jobs[j];
-        if (jobs[j].r < 1 || jobs[j].r > 64 || jobs[j].m < jobs[j].r || jobs[j].m > 128) return hipErrorInvalidValue;
+        if (jobs[j].r < 1 || jobs[j].r > 64 || jobs[j].m < jobs[j].r || jobs[j].m > 256) return hipErrorInvalidValue;
         const size_t need = (size_t)jobs[j].r * jobs[j].m * sizeof(double);
         if (need > lds) lds = need;
     }
@@ -1899,7 +1909,7 @@ hipError_t vg_eigh_setup() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_rowqr_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);      // r x m <= 64 x 256 doubles
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);

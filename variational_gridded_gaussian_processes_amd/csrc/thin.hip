@@ -83,7 +83,7 @@ enum { B_W1 = 0, B_W1T, B_W2, B_W2T, B_E1, B_F1, B_E2, B_F2, B_P0, B_P1, B_P2, B
 __global__ __launch_bounds__(1024) void vg_thin_tail_kernel(const VgThinTail tt) {
     extern __shared__ __attribute__((aligned(16))) double vt_dyn[];
     __shared__ double red[16 * VT_NBIG], tot[VT_NBIG + VT_NSMALL];
-    __shared__ double dg[4][128];                       // diagonals of G0_1, H0_1, G0_2, H0_2 (traces over ALL directions)
+    __shared__ double dg[4][256];                       // diagonals of G0_1, H0_1, G0_2, H0_2 (traces over ALL directions)
     __shared__ double l1s[VT_MAXR], l2s[VT_MAXR], rs1[VT_MAXR], rl1[VT_MAXR], rs2[VT_MAXR], rl2[VT_MAXR];
     __shared__ VtTask tk[18];
     __shared__ double stage[16];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(1024) void vg_thin_tail_kernel(const VgThinTail tt)
     if (tid >= 76 && tid < 78) jit_s[tid - 76] = tt.jit[tid - 76] ? *tt.jit[tid - 76] : 0.0;
     if (tid == 78) pf_s = tt.peer_fail ? *tt.peer_fail : 0.0;
     if (tid == 79) seq_s = tt.theta[5];
-    if (tid >= 128 && tid < 256) {                       // (m <= 128: one diagonal element per lane and matrix)
+    if (tid >= 128 && tid < 384) {                       // (m <= 256: one diagonal element per lane and matrix)
         const int i = tid - 128;
         dg[0][i] = i < tt.m1 ? tt.G1[(long)i * tt.m1 + i] : 0.0; dg[1][i] = i < tt.m1 ? tt.H1[(long)i * tt.m1 + i] : 0.0;
         dg[2][i] = i < tt.m2 ? tt.G2[(long)i * tt.m2 + i] : 0.0; dg[3][i] = i < tt.m2 ? tt.H2[(long)i * tt.m2 + i] : 0.0;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void vg_thin_tail_kernel(const VgThinTail tt)
             T[9] = l2s[l] > VG_EIG_RANK_CUT * l2s[0] ? 1.0 : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) T[10 + q] = dg[q][l] + dg[q][l + 64];
+        for (int q = 0; q < 4; ++q) T[10 + q] = (dg[q][l] + dg[q][l + 64]) + (dg[q][l + 128] + dg[q][l + 192]);
         vt_wave_sum<VT_NSMALL>(T);
         if (l == 0) {
 #pragma unroll
@@ -314,8 +314,8 @@ hipError_t vg_thin_tail_setup() {
 }
 
 hipError_t vg_thin_tail_launch(const VgThinTail* tt, hipStream_t st) {
-    if (tt->r1 < 1 || tt->r2 < 1 || tt->r1 > VT_MAXR || tt->r2 > VT_MAXR || tt->r1 > tt->m1 || tt->r2 > tt->m2 || tt->m1 > 128 ||
-        tt->m2 > 128)
+    if (tt->r1 < 1 || tt->r2 < 1 || tt->r1 > VT_MAXR || tt->r2 > VT_MAXR || tt->r1 > tt->m1 || tt->r2 > tt->m2 || tt->m1 > 256 ||
+        tt->m2 > 256)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(vg_thin_tail_kernel, dim3(1), dim3(1024), vg_thin_tail_lds(tt->r1, tt->r2), st, *tt);
     return hipGetLastError();
