@@ -27,6 +27,8 @@ Prints ONE JSON line on rank 0 (see the task contract): metric/value/... plus
   stages_us         per-launch-group breakdown of one step (HIP events on the launch stream, plain launches)
   cold_ms_per_step  the same loop with the eigensolver's warm start off
   m_d_sweep         ms per step for m_d in {32, 64, 128, 256}
+  families          ms per step of Matern-3/2, 5/2 at m_d = 128 and Matern-3/2, 1/2 at m_d = 256 (refinement / Newton chain)
+  fit_predict_loop  ms per iteration of a loop that calls q_v() after every step
   posterior_1M_points  vggp_posterior (mean + variance) at 2^20 scattered test points after a headline step
   svgp_train_z      ms per optimiser iteration of an SVGP whose inducing points are trained (step + Z-gradient + in-place move)
   scattered         vggp_elbo_step_scattered: ms per step for 100 000 points that form no grid (B0 cells, m_d = 32)
@@ -202,17 +204,34 @@ def pmc_traffic(n1, n2_loc, m):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
     runs of this same command, profiles/r2_pmc_traffic.json written by tools/pmc_traffic.py).  None -- and the reason -- when
     the passes are absent, were taken on another kernel source than HEAD's, or on another launch shape."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
     except Exception:
-        return None, "no committed PMC passes (profiles/r2_pmc_traffic.json)"
+        return None, "no committed PMC passes (profiles/r3_pmc_traffic.json)"
     if d.get("source_sha") != source_sha():
         return None, f"stale: passes taken on kernel source {d.get('source_sha')}, HEAD is {source_sha()}"
     if d.get("shape") != [n1, n2_loc, m]:
         return None, f"passes taken on shape {d.get('shape')}"
-    return d, "profiles/r2_pmc_traffic.json"
+    return d, "profiles/" + os.path.basename(path)
+
+
+def rocprof_kernel_us(kernel):
+    """Average duration (us) of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/r3_step_kernel_stats.csv), or None."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r3_step_kernel_stats.csv")
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Name", "").startswith(kernel):
+                    return float(row["AverageNs"]) / 1e3
+    except Exception:
+        return None
+    return None
 
 
 def _visible_devices():
@@ -469,10 +488,14 @@ def main():
             step_flops = sum(flops.values())
             alg_bytes = 8 * (n1 * n2_loc + 2 * m * n2_loc + 2 * m * n1)       # Y once, [B2;V2] once, the un-split output S
             tr, tr_src = pmc_traffic(n1, n2_loc, m)
+            rp_us = rocprof_kernel_us(eng.project_kernel_name()) if (n1, n2_loc, m) == (1024, 1024, 128) else None
             out["roofline"] = {
                 "kernel": f"{eng.project_kernel_name()} (launch group '{PROJ}': the only pass over Y)",
                 "bound": "mfma", "achieved": proj_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": proj_tflops / FP64_PEAK_TFLOPS,
+                "frac_events": proj_tflops / FP64_PEAK_TFLOPS,
+                "frac_rocprof": (flops[PROJ] / (rp_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS) if rp_us else None,
+                "avg_launch_us_rocprof": rp_us,
                 "traffic": tr["bytes"] if tr else None, "traffic_source": tr_src, "traffic_detail": tr,
                 "flops_per_launch": flops[PROJ], "avg_launch_us": stages_us[PROJ],
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -486,6 +509,8 @@ def main():
             out["cold_ms_per_step"] = timed_loop(eng, Y, yy, args.kind, x1, x2, m, warm=False, steps=40, warmup=5)
             out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=40 if md < 256 else 12,
                                                     warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
+            out["families"] = families_bench(eng, Y, yy, x1, x2)
+            out["fit_predict_loop"] = fit_predict_bench(eng, Y, yy, args.kind, x1, x2, m)
             out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
             out["posterior_1M_points"] = posterior_bench(eng, Y, yy, args.kind, x1, x2, m)
             out["svgp_train_z"] = trainz_bench(eng, Y, yy, x1, x2, m)
@@ -526,6 +551,40 @@ def timed_loop(eng, Y, yy, kind, x1, x2, m, warm, steps, warmup):
         one()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
+
+
+def families_bench(eng, Y, yy, x1, x2):
+    """Fit-loop ms per step of the other kernel families on the same 1024 x 1024 grid: full-rank spectra take
+    the first-order refinement + polish (Matern-1/2, 3/2 at m_d = 128) or the Newton chain (Matern-5/2 at 128; everything at
+    m_d = 256, which is beyond the LDS eigensolver)."""
+    out = {}
+    for kind, m in (("matern32", 128), ("matern52", 128), ("matern32", 256), ("matern12", 256)):
+        out[f"{kind}_md{m}"] = timed_loop(eng, Y, yy, kind, x1, x2, m, warm=True, steps=60, warmup=20)
+    return out
+
+
+def fit_predict_bench(eng, Y, yy, kind, x1, x2, m, iters=30):
+    """A loop that alternates fit and predict: one ELBO step + q_v() per iteration.  Every read-out after a warm step re-runs the
+    finish half with a cold eigensolve, so this is about step + 1 ms."""
+    import torch
+    g = np.linspace(0, 1, m)
+    eng.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=True)
+    opt = Adam(raw_start(), lr=0.01)
+
+    def one():
+        raw = opt.x
+        e, gr, info = eng.elbo_step(Y, yy, theta_from_raw(raw.copy()))
+        opt.step(-(gr / (1.0 + np.exp(-raw))))
+        return eng.qv()
+
+    for _ in range(6):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    return {"ms_per_iteration": (time.perf_counter() - t0) / iters * 1e3, "what": "elbo_step + qv (mean and variance of q(v)) per iteration"}
 
 
 def slab_bench(eng, D, kind, m, n1=4096, n2=1024):

@@ -28,6 +28,11 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 #include "ctx.h"
 #include "factor_elem.h"
 #define VG_CHOL_MAXJOBS_HOST 8
+#define VG_NEWTON_TOL 1e-12      // off-diagonal threshold of the Newton chain's rotations, relative to ||Gw||_F / m
+#define VG_NEWTON_NOISE 1e-13    // diagonal entries below this fraction of the largest are "at the rounding floor" (VgRefineJob::noise)
+#define VG_NEWTON_ACCEPT 1e-11   // ... of its convergence check: Gw = S G S^T comes out of two GEMMs with ~ eps sqrt(m) ||G|| of rounding noise per
+                                 // element, 2e-15 ||G|| at m = 256 against 4e-15 ||G||_F for 1e-12 -- the chain converged TO the threshold and
+                                 // missed by a hair (measured: 10 log10(offdiag / thr) = 0 at every miss); the ELBO sees such elements at second order
 
 static void graphs_clear(vggp_ctx* c);
 static int vg_quiesce(vggp_ctx* c);
@@ -324,6 +329,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     c->pred_consumed = false;
     c->acc_valid = false; c->last_warm = false; c->last_slabs = false; c->last_payload = nullptr;
     c->last_thin = false; c->thin_off = false;
+    c->cur_newton = 0; c->last_newton = false; c->newton_next = false; c->newton_block = 0; c->newton_iters = 3;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -702,7 +708,8 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
 static bool vg_sub_ident() { static const bool ex = getenv("VGGP_SUB_EXTRAP") != nullptr; return !ex; }
 
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
-                          bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false, bool thin = false) {
+                          bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false, bool thin = false,
+                          int newton = 0) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 6 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -909,6 +916,109 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_add(&g, d.TM, d.m, 1, d.E, 1, d.m, d.Gw, d.m, d.m, d.m, d.m);
         }
         VG_HIP(vg_gemm_launch(&g, st));
+    } else if (warm && newton > 0) {
+        // ---- Newton chain: full-rank Gram matrices whose warm start is too far off for the first-order refinement (or too large
+        // for the LDS eigensolver, m > 128).  From the start basis S (rows), Gw = S G S^T; then `newton` times
+        //     E_ij = g_ij / (g_jj - g_ii) (skew, elements above the threshold),  S <- (I + E + E^2 / 2) S,
+        //     one Newton-Schulz step (not after the last iteration),  Gw = S G S^T
+        // -- quadratic: |E| 1e-1 -> 1e-2 -> 1e-4 -> 1e-8 -- every product a batched MFMA GEMM over the whole chip, no single-workgroup
+        // sweep.  The last look at Gw (vg_newton_check_kernel) takes the eigenvalues from its diagonal and raises the retry bit when
+        // an off-diagonal element is still above the threshold or a rotation was too large (a crossing, a degenerate pair): the
+        // host then repeats the step on the regular chain.  Eigenpairs stay in the ORDER of the start basis (no sort).
+        const double* Gr[2] = {G0[0], G0[1]};
+        int grn[2] = {ghn[0], ghn[1]};
+        double* gdst[2] = {d1.GH, c->payload};
+        const double* Scur[2] = {extrap ? d1.Fp : d1.QtPrev, extrap ? d2.Fp : d2.QtPrev};
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            vg_gemm_add(&g, Scur[k], d.m, 1, G0[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            if (from_slabs && ghn[k] > 1) {                  // reduced copies: G is read once per iteration, H in the rotation
+                vg_gemm_add(&g, d.Id, d.m, 1, G0[k], d.m, 1, gdst[k], d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+                vg_gemm_add(&g, d.Id, d.m, 1, H0[k], d.m, 1, gdst[k] + (long)d.m * d.m, d.m, d.m, d.m, d.m, 1, 0, ghn[k], ghs[k]);
+            }
+        }
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(8);
+        for (int k = 0; k < 2; ++k)
+            if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; Hr[k] = gdst[k] + (long)c->d[k].m * c->d[k].m; hrn[k] = 1; }
+        vg_gemm_init(&g);
+        for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; vg_gemm_add(&g, d.TM, d.m, 1, Scur[k], 1, d.m, d.Gw, d.m, d.m, d.m, d.m); }
+        VG_HIP(vg_gemm_launch(&g, st));
+        VG_MARK(12);
+        int bi = 0;                                                           // rotation of the three basis buffers E, X, F
+        for (int it = 0; it < newton; ++it) {
+            VgRefineJob rj[2];
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, VG_NEWTON_TOL};
+                rj[k].emax = 0.3; rj[k].flag = d.counters2; rj[k].noise = VG_NEWTON_NOISE;
+            }
+            const VgGemmBatch* rd = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
+            VG_HIP(vg_refine_launch(rj, 2, st, rd));                           // E -> U, I + E -> TH  (+ riders: S, then [C;C1;C2])
+            if (rd) ++ride_stage;
+            VG_MARK(9);
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; vg_gemm_add(&g, d.U, d.m, 1, d.U, d.m, 1, d.TH, d.m, d.m, d.m, d.m, 1, 0, 1, 0, 0.5, 1); }   // TH += E^2 / 2
+            VG_HIP(vg_gemm_launch(&g, st));
+            double* Snew[2];
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                double* bufs[3] = {d.E, d.X, d.F};
+                Snew[k] = bufs[bi];
+                vg_gemm_add(&g, d.TH, d.m, 1, Scur[k], d.m, 1, Snew[k], d.m, d.m, d.m, d.m);                 // (I + E + E^2/2) S
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+            bi = (bi + 1) % 3;
+            if (it + 1 < newton) {                                            // Newton-Schulz: S <- 1.5 S - 0.5 (S S^T) S
+                double* Sns[2];
+                vg_gemm_init(&g);
+                for (int k = 0; k < 2; ++k) {
+                    VgDim& d = c->d[k];
+                    double* bufs[3] = {d.E, d.X, d.F};
+                    Sns[k] = bufs[bi];
+                    vg_gemm_add(&g, Snew[k], d.m, 1, Snew[k], 1, d.m, d.TM, d.m, d.m, d.m, d.m);             // W = S S^T
+                    vg_gemm_add(&g, d.Id, d.m, 1, Snew[k], d.m, 1, Sns[k], d.m, d.m, d.m, d.m, 1, 0, 1, 0, 1.5, 0);
+                }
+                VG_HIP(vg_gemm_launch(&g, st));
+                vg_gemm_init(&g);
+                for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; vg_gemm_add(&g, d.TM, d.m, 1, Snew[k], d.m, 1, Sns[k], d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1); }
+                VG_HIP(vg_gemm_launch(&g, st));
+                bi = (bi + 1) % 3;
+                for (int k = 0; k < 2; ++k) Scur[k] = Sns[k];
+            } else {
+                for (int k = 0; k < 2; ++k) Scur[k] = Snew[k];
+            }
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; vg_gemm_add(&g, Scur[k], d.m, 1, Gr[k], d.m, 1, d.TM, d.m, d.m, d.m, d.m, 1, 0, grn[k], ghs[k]); }
+            VG_HIP(vg_gemm_launch(&g, st));
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; vg_gemm_add(&g, d.TM, d.m, 1, Scur[k], 1, d.m, d.Gw, d.m, d.m, d.m, d.m); }
+            VG_HIP(vg_gemm_launch(&g, st));
+        }
+        VgNewtonCheckJob nj[2];
+        for (int k = 0; k < 2; ++k) {
+            VgDim& d = c->d[k];
+            nj[k] = VgNewtonCheckJob{d.Gw, d.lam0, d.counters, d.status + 1, d.counters2, d.m, newton, VG_NEWTON_ACCEPT, VG_NEWTON_NOISE};
+            VG_HIP(hipMemcpyAsync(d.Qt, Scur[k], sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
+        }
+        VG_HIP(vg_newton_check_launch(nj, 2, st));
+        {   // converged: QtPrev2 <- QtPrev (the basis before last, for the next extrapolation), QtPrev <- the new basis; a miss leaves
+            // both alone, and the host repeats the step on the regular chain from the same warm start
+            const int* er[2] = {d1.status + 1, d2.status + 1};
+            const double* sa[2] = {Scur[0], Scur[1]};
+            double* da[2] = {d1.QtPrev, d2.QtPrev};
+            const double* sb[2] = {d1.QtPrev, d2.QtPrev};
+            double* db[2] = {d1.QtPrev2, d2.QtPrev2};
+            const long nn[2] = {m1 * m1, m2 * m2};
+            VG_HIP(vg_copy_if_launch(er, sa, da, sb, db, nn, 2, st));
+        }
+        VG_MARK(13);
+        while (ride && ride_stage < 2) {                                      // (fewer than two iterations: what is still pending)
+            VG_HIP(vg_gemm_launch(ride_stage == 0 ? &c->ride_proj : &c->ride_cc, st));
+            ++ride_stage;
+        }
     } else if (warm) {
         const double* Gr[2] = {G0[0], G0[1]};
         int grn[2] = {ghn[0], ghn[1]};
@@ -993,9 +1103,11 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     // riders of the main solve: whichever of the two projection launches is next (S when no earlier launch of the chain took
     // it; [C;C1;C2] when the refinement launch carried S); what is still pending afterwards runs as a launch of its own
     const VgGemmBatch* mr = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
-    VG_HIP(vg_eigh_launch(ej, 2, st, mr));
-    VG_MARK(13);
-    if (mr) ++ride_stage;
+    if (!(warm && newton > 0)) {              // (the Newton chain has left lam0, Qt, QtPrev itself)
+        VG_HIP(vg_eigh_launch(ej, 2, st, mr));
+        VG_MARK(13);
+        if (mr) ++ride_stage;
+    }
     if (ride && ride_stage == 1) { VG_HIP(vg_gemm_launch(&c->ride_cc, st)); ride_stage = 2; }
     c->ride_pending = false;
     if (from_slabs) VG_JOIN_WAIT(1);          // fused step: the projection branch (S, C slabs) ran beside the eigensolver chain
@@ -1093,9 +1205,9 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
        VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_FINISH_WARM_T, VG_G_STEP_WARM_T,
-       VG_G_COUNT };
+       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_COUNT };
 static_assert(VG_G_COUNT <= 16, "vggp_ctx::gexec");
-// _T: thin chain (subspace start without a complement basis, thin.hip)
+// _T: thin chain (subspace start without a complement basis, thin.hip); _N: Newton chain
 // _S: subspace start (see finish_enqueue)
 // _X: warm start from the extrapolated basis; _XR: ... refined to first order before the eigensolver (see finish_enqueue)
 
@@ -1141,7 +1253,7 @@ static bool vg_extrapolate(const vggp_ctx* c) {
 
 // start-basis strategy of this step; switching the subspace mode on puts the identity into U (the partials then run a plain
 // Newton-Schulz clean-up of QtPrev through the extrapolation products) and drops stale _S graphs when the ranks moved
-struct VgStart { bool extrap, refine, subspace, thin; };
+struct VgStart { bool extrap, refine, subspace, thin; int newton; };
 // The thin chain needs: ranks known and small, the leading rows of QtPrev valid, the step's payload owned by the context (its
 // read-outs re-run the finish half cold on the resident G, H, C), and no caller that wanted the full m-space state of a warm step.
 static bool vg_thin_ok(const vggp_ctx* c, bool own_payload) {
@@ -1169,14 +1281,31 @@ static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out
     // (the full subspace chain -- complement basis, sparse-first main solve -- lives in the LDS eigensolver body: m <= 128)
     const bool lds_sized = c->d[0].m <= 128 && c->d[1].m <= 128;
     out->subspace = out->thin || (lds_sized && warm && out->extrap && c->sub_next && c->d[0].sub_r > 0 && c->d[1].sub_r > 0);
-    out->refine = warm && !out->subspace && vg_refine(c, out->extrap);
+    // Newton chain: full-rank warm starts beyond the LDS eigensolver (m > 128) or where the last warm step still needed Jacobi rounds
+    {
+        static const bool off = getenv("VGGP_NO_NEWTON_CHAIN") != nullptr;
+        static const char* ite = getenv("VGGP_NEWTON_ITERS");
+        const bool big = c->d[0].m > 128 || c->d[1].m > 128;
+        const bool want = warm && !out->subspace && out->extrap && !off && c->newton_block == 0 && (big || c->newton_next) &&
+                          !(c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) && c->d[0].m >= 8 && c->d[1].m >= 8;
+        out->newton = want ? (ite ? atoi(ite) : c->newton_iters) : 0;
+        if (c->newton_block > 0) --c->newton_block;
+    }
+    out->refine = warm && !out->subspace && !out->newton && vg_refine(c, out->extrap);
     c->sub_mode = out->subspace;
     if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
         for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S, (int)VG_G_FINISH_WARM_T, (int)VG_G_STEP_WARM_T})
             if (c->gexec[v]) { (void)vg_quiesce(c); (void)hipGraphExecDestroy(c->gexec[v]); c->gexec[v] = nullptr; c->gkey[v] = VgGraphKey(); }
         c->sub_r_cap[0] = c->d[0].sub_r; c->sub_r_cap[1] = c->d[1].sub_r;
     }
+    if (out->newton && out->newton != c->newton_cap) {          // the _N graphs hold a fixed number of iterations
+        for (int v : {(int)VG_G_FINISH_WARM_N, (int)VG_G_STEP_WARM_N})
+            if (c->gexec[v]) { (void)vg_quiesce(c); (void)hipGraphExecDestroy(c->gexec[v]); c->gexec[v] = nullptr; c->gkey[v] = VgGraphKey(); }
+        c->newton_cap = out->newton;
+    }
     c->cur_thin = out->thin;
+    c->cur_extrap = out->extrap;
+    c->cur_newton = out->newton;
     c->cur_r[0] = c->d[0].sub_r; c->cur_r[1] = c->d[1].sub_r;
     return VGGP_OK;
 }
@@ -1305,12 +1434,27 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     // refine the next start only where it can replace the last sweep: both dimensions polished after at most one sweep
     c->refine_next = !status && ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1) &&
                      (c->h_out->counters[0][1] & 0xff) <= 1 && (c->h_out->counters[1][1] & 0xff) <= 1;
+    if (status == VG_ESUBMISS && c->cur_newton) {
+        // the Newton chain missed: it has not touched the stored bases -- repeat on the regular chain from the same warm start
+        static const bool dbg = getenv("VGGP_NEWTON_DBG") != nullptr;
+        if (dbg)
+            fprintf(stderr, "[vggp] step %ld: Newton chain (%d iterations) missed: dim1 flags %d, 10 log10(offdiag / thr) = %d; dim2 flags %d, %d\n",
+                    c->seq, c->cur_newton, c->h_out->counters[0][3] & 0xff, (c->h_out->counters[0][3] >> 8) - 100,
+                    c->h_out->counters[1][3] & 0xff, (c->h_out->counters[1][3] >> 8) - 100);
+        c->newton_block = 16; c->newton_next = false;
+        if (c->newton_iters < 4) ++c->newton_iters;
+        c->have_step = false;
+        return VG_ESUBMISS;
+    }
     if (status) {          // the bases written by this step are not trustworthy: the next step starts cold
         c->warm_run = 0;
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
         c->have_step = false;
     }
-    if (status == VG_ESUBMISS) { c->sub_next = false; return VG_ESUBMISS; }      // (the caller repeats the step; the warm start was reset above)
+    if (status == VG_ESUBMISS) {            // (the caller repeats the step; the warm start was reset above)
+        c->sub_next = false;
+        return VG_ESUBMISS;
+    }
     if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
     if (status == VGGP_ENOCONV) { vg_set_error("Jacobi eigensolver did not converge"); return VGGP_ENOCONV; }
     for (int k = 0; k < 2; ++k) {
@@ -1319,6 +1463,16 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         c->d[k].thin_rows = c->cur_thin ? c->cur_r[k] : c->d[k].m;      // ... all of it, or the range rows of a thin step
     }
     c->last_thin = c->cur_thin;
+    // (the Newton chain keeps the eigenpairs in the order of its start basis, the eigensolver sorts: after a crossing the two stored
+    //  bases of a chain switch may not correspond row by row -- the extrapolated start is then poor, the chain that receives it
+    //  notices: the regular one sweeps, the Newton chain misses and the step is repeated)
+    c->last_newton = c->cur_newton > 0;
+    // next step: stay on the Newton chain while it works; move to it when a warm step of the regular chain still needed rounds
+    {
+        const bool polished = ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1);
+        c->newton_next = c->cur_newton > 0 ||
+                         (c->last_warm && c->cur_extrap && !c->cur_thin && !polished && (c->h_out->counters[0][0] + c->h_out->counters[1][0]) > 0);
+    }
     if (++c->warm_run >= 512) {                                // periodic cold restart: bounds the drift of orthogonality
         c->warm_run = 0;
         for (int k = 0; k < 2; ++k) c->d[k].have_prev = c->d[k].have_prev2 = false;
@@ -1373,9 +1527,10 @@ static int elbo_finish_once(vggp_ctx* c, const double* payload, double yy_total,
     VgStart sp;                                   // same state as at the matching vggp_elbo_partials call
     if ((rc = vg_start_prepare(c, warm, st, &sp, false))) return rc;
     const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace;
-    rc = run_graph(c, warm ? (subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
+    const int newton = sp.newton;
+    rc = run_graph(c, warm ? (newton ? VG_G_FINISH_WARM_N : subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
                             : VG_G_FINISH_COLD, key, st,
-                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap, refine, subspace); });
+                   [&] { return finish_enqueue(c, payload, yy_total, warm, st, true, false, extrap, refine, subspace, false, newton); });
     if (rc) return rc;
     c->last_warm = warm; c->last_slabs = false; c->last_payload = payload; c->last_yy = yy_total;
     return finish_collect(c, elbo_out, grad_out, info, st);
@@ -1414,6 +1569,7 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
     VgStart sp;
     if ((rc = vg_start_prepare(c, warm, st, &sp, true))) return rc;
     const bool extrap = sp.extrap, refine = sp.refine, subspace = sp.subspace, thin = sp.thin;
+    const int newton = sp.newton;
     const bool apply_ns = extrap && !c->pred_consumed;
     if (c->n_ranks > 1 || c->comm || c->cb) {
         // row-sharded job: partials graph -> the context's all-reduce of the packed payload (RCCL: enqueued on this stream)
@@ -1448,18 +1604,18 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         if (extrap) c->pred_consumed = true;
         c->have_partials = true;
         if ((rc = vg_allreduce(c, c->payload, c->payload_len + 1, st))) return rc;
-        rc = run_graph(c, warm ? (thin ? VG_G_FINISH_WARM_T : subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
+        rc = run_graph(c, warm ? (thin ? VG_G_FINISH_WARM_T : newton ? VG_G_FINISH_WARM_N : subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
                                 : VG_G_FINISH_COLD, kf, st,
-                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace, thin); });
+                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace, thin, newton); });
         if (rc) return rc;
         c->last_warm = warm; c->last_slabs = false; c->last_payload = c->payload; c->last_yy = yy_total;
         return finish_collect(c, elbo_out, grad_out, info, st);
     }
     const VgGraphKey key{Y, c->payload, yy_total};
-    rc = run_graph(c, warm ? (thin ? VG_G_STEP_WARM_T : subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
+    rc = run_graph(c, warm ? (thin ? VG_G_STEP_WARM_T : newton ? VG_G_STEP_WARM_N : subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
                             : VG_G_STEP_COLD, key, st, [&] {
         const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace, thin);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace, thin, newton);
     }, extrap && !apply_ns);
     if (rc) return rc;
     if (extrap) c->pred_consumed = true;

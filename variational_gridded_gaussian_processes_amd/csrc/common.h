@@ -207,7 +207,20 @@ hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st, co
 hipError_t vg_identity_launch(double* A, int m, hipStream_t st);
 // First-order refinement of a warm start (eigh.hip): from Gw = S G S^T, E_ij = g_ij / (g_ii - g_jj) for the elements above
 // the eigensolver's threshold; outputs E and R1 = I + E (both [m][m]); E = 0, R1 = I when some |E_ij| > 1e-3.
-struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol; };
+struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol;
+                     double emax = 0.0;      // largest rotation accepted (0: VG_POLISH_EMAX = 1e-3, the polish's limit)
+                     int* flag = nullptr;    // optional: bit 1 is OR-ed in when the start was rejected (some |E_ij| > emax, NaN)
+                     double noise = 0.0;     // > 0: pairs whose two diagonal entries are both below noise * max diagonal are left alone
+                                             // (a cluster at the rounding floor: any orthonormal basis of it serves -- what the ELBO sees of
+                                             // it is its trace -- and its quotients g_ij / (g_jj - g_ii) are noise over noise)
+};
+// Newton chain (api.hip finish_enqueue): after the last iteration -- eigenvalues = diag(Gw), convergence check (largest
+// off-diagonal element against tol * ||Gw||_F / m), numerical rank; counters [0] = 0, [1] = iterations | rank << 8, [2] = 0,
+// [3] = 0; bit 1 of *err (-> VG_ESUBMISS: the host repeats the step on the regular chain) when not converged or rejected.
+struct VgNewtonCheckJob { const double* Gw; double* lam; int* counters; int* err; const int* flag; int m; int iters; double tol; double noise; };
+hipError_t vg_newton_check_launch(const VgNewtonCheckJob* jobs, int njobs, hipStream_t st);
+hipError_t vg_copy_if_launch(const int* const* err, const double* const* src_a, double* const* dst_a, const double* const* src_b,
+                             double* const* dst_b, const long* n, int njobs, hipStream_t st);
 hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);
 size_t vg_eigh_log_bytes(int m);     // log capacity needed for an m x m problem (scalar or block variant)
 hipError_t vg_eigh_launch(const VgEigJob* jobs, int njobs, hipStream_t st, const VgGemmBatch* rider = nullptr);

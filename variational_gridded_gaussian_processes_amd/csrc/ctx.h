@@ -96,6 +96,11 @@ struct vggp_ctx {
     double *tCV = nullptr, *tAC = nullptr;   // thin chain: {C, C1, C2} V1_2^T  [3 m1][r2]  and  V1_1 (.)  [3][r1][r2]
     bool cur_thin = false;            // the step in flight runs the thin chain, with these ranks (vg_start_prepare -> finish_collect)
     int cur_r[2] = {0, 0};
+    bool cur_extrap = false;          // the step in flight starts from the extrapolated basis
+    int cur_newton = 0;               // Newton-chain iterations of the step in flight (0: another chain)
+    bool last_newton = false, newton_next = false;
+    int newton_block = 0;             // steps for which the Newton chain stays off after a miss
+    int newton_iters = 3, newton_cap = 0;
     bool last_thin = false;           // the last finished step ran the thin chain: QtPrev holds r rows, the m-space state (beta, 1/D, E, F) is not there
     bool thin_off = false;            // a caller needed the full m-space state of a warm step (vggp_zgrad): keep to the full chain from now on
     bool sub_mode = false;            // the current step uses the subspace start (U then holds the identity)         // the last step ended in the polish in both dimensions: refine the next start basis

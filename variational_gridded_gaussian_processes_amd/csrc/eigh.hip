@@ -1785,6 +1785,7 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
     }
     const VgRefineJob& J = a.job[blockIdx.x];
     const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double emax = J.emax > 0.0 ? J.emax : VG_POLISH_EMAX;
     if (m <= 128) {
         // One batch of loads for the whole matrix (16 elements per thread, coalesced); the three passes below then run on
         // registers and LDS.  Gw comes straight from the previous kernel: the three dependent passes over global memory of the
@@ -1810,6 +1811,12 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
         double fro = 0.0;
         for (int w = 0; w < 16; ++w) fro += red[w];
         const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
+        double nfloor = -1.0;                                   // diagonal entries at or below this are "at the rounding floor"
+        if (J.noise > 0.0) {
+            double dm = fmax(lane < m ? fabs(dg[lane]) : 0.0, lane + 64 < m ? fabs(dg[lane + 64]) : 0.0);
+            for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off));
+            nfloor = J.noise * dm;
+        }
         __syncthreads();
         // every thread forms the quotient of ITS elements from the lower-triangle value (E is exactly skew), coalesced stores
         double e[16], mE = 0.0;
@@ -1822,10 +1829,10 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
                 if (i != j) {
                     const int lo = i > j ? i : j, hi = i > j ? j : i;
                     const double gl = vr_dyn[vg_tri(lo) + hi];
-                    if (fabs(gl) > thr) {
+                    if (fabs(gl) > thr && !(fabs(dg[lo]) <= nfloor && fabs(dg[hi]) <= nfloor)) {
                         const double q = gl / (dg[lo] - dg[hi]);
                         mE = fmax(mE, fabs(q));
-                        if (!(fabs(q) <= VG_POLISH_EMAX)) mE = 1e300;          // NaN / inf
+                        if (!(fabs(q) <= emax)) mE = 1e300;                    // NaN / inf
                         e[u] = i > j ? q : -q;
                     }
                 }
@@ -1836,7 +1843,8 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
         __syncthreads();
         mE = 0.0;
         for (int w = 0; w < 16; ++w) mE = fmax(mE, red[w]);
-        const bool ok = mE <= VG_POLISH_EMAX;
+        const bool ok = mE <= emax;
+        if (!ok && J.flag && tid == 0) atomicOr(J.flag, 2);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int idx = tid + u * 1024;
@@ -1860,6 +1868,13 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
     double fro = 0.0;
     for (int w = 0; w < 16; ++w) fro += red[w];
     const double thr = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(fro) / (double)m;
+    double nfloor = -1.0;
+    if (J.noise > 0.0) {
+        double dm = 0.0;
+        for (int i = lane; i < m; i += 64) dm = fmax(dm, fabs(dg[i]));
+        for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off));
+        nfloor = J.noise * dm;
+    }
     __syncthreads();
     // E from the lower triangle (the value at (i, j), i > j, decides for (j, i) too: E is exactly skew); the transposed
     // element is written by the same lane, so one pass computes every quotient once
@@ -1867,19 +1882,20 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
     for (int i = wave; i < m; i += 16)
         for (int j = lane; j < i; j += 64) {
             const double g = J.Gw[i * m + j];
-            if (fabs(g) > thr) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
+            if (fabs(g) > thr && !(fabs(dg[i]) <= nfloor && fabs(dg[j]) <= nfloor)) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
         }
     for (int off = 32; off > 0; off >>= 1) mE = fmax(mE, __shfl_xor(mE, off));
     if (lane == 0) red[wave] = mE;
     __syncthreads();
     mE = 0.0;
     for (int w = 0; w < 16; ++w) mE = fmax(mE, red[w]);
-    const bool ok = mE <= VG_POLISH_EMAX;                   // false also for NaN / inf
+    const bool ok = mE <= emax;                             // false also for NaN / inf
+    if (!ok && J.flag && tid == 0) atomicOr(J.flag, 2);
     for (int i = wave; i < m; i += 16)
         for (int j = lane; j <= i; j += 64) {
             if (j == i) { J.E[i * m + i] = 0.0; J.R1[i * m + i] = 1.0; continue; }
             const double g = J.Gw[i * m + j];
-            const double e = (ok && fabs(g) > thr) ? g / (dg[i] - dg[j]) : 0.0;
+            const double e = (ok && fabs(g) > thr && !(fabs(dg[i]) <= nfloor && fabs(dg[j]) <= nfloor)) ? g / (dg[i] - dg[j]) : 0.0;
             J.E[i * m + j] = e;  J.R1[i * m + j] = e;
             J.E[j * m + i] = -e; J.R1[j * m + i] = -e;
         }
@@ -1901,6 +1917,78 @@ hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st, 
         if (jobs[j].m <= 128) lds = std::max(lds, (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double));
     if (rb.total_tiles > 0) lds = std::max(lds, (size_t)(2 * VgTile<64, 16>::TILE * sizeof(double)));
     hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs + rb.total_tiles), dim3(1024), lds, st, a, rb);
+    return hipGetLastError();
+}
+
+// ---- Newton chain: the last look at Gw = S G S^T ------------------------------------------------------------------------------
+struct VgNewtonCheckArgs { VgNewtonCheckJob job[2]; int njobs; };
+__global__ __launch_bounds__(1024) void vg_newton_check_kernel(const VgNewtonCheckArgs a) {
+    __shared__ double red[3 * 16];
+    const VgNewtonCheckJob& J = a.job[blockIdx.x];
+    const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double dgc[256];
+    double ss = 0.0, mo = 0.0, lmax = 0.0;
+    for (int i = tid; i < m; i += 1024) { const double g = J.Gw[(long)i * m + i]; dgc[i] = g; J.lam[i] = g; }
+    __syncthreads();
+    for (int i = lane; i < m; i += 64) lmax = fmax(lmax, dgc[i]);
+    for (int off = 32; off > 0; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
+    const double nfloor = J.noise > 0.0 ? J.noise * lmax : -1.0;
+    for (int i = wave; i < m; i += 16)
+        for (int j = lane; j < m; j += 64) {
+            const double g = J.Gw[(long)i * m + j];
+            ss += g * g;
+            if (i != j && !(fabs(dgc[i]) <= nfloor && fabs(dgc[j]) <= nfloor)) mo = fmax(mo, fabs(g));
+        }
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); mo = fmax(mo, __shfl_xor(mo, off)); }
+    if (lane == 0) { red[wave] = ss; red[16 + wave] = mo; }
+    __syncthreads();
+    double fro = 0.0; mo = 0.0;
+    for (int w = 0; w < 16; ++w) { fro += red[w]; mo = fmax(mo, red[16 + w]); }
+    __syncthreads();
+    int nr = 0;
+    for (int i = tid; i < m; i += 1024) nr += J.Gw[(long)i * m + i] > VG_EIG_RANK_CUT * lmax ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) nr += __shfl_xor(nr, off);
+    if (lane == 0) red[wave] = (double)nr;
+    __syncthreads();
+    if (tid == 0) {
+        int nrank = 0;
+        for (int w = 0; w < 16; ++w) nrank += (int)red[w];
+        const double thr = J.tol * sqrt(fro) / (double)m;
+        const bool bad = !(mo <= thr) || (J.flag && (*J.flag & 2));
+        // counters[3]: diagnostics of a miss -- bit 1: a rotation was rejected, bit 2: not converged; bits 8..: -log10 of the largest
+        // off-diagonal element relative to the threshold (how far from convergence)
+        const int rej = (J.flag && (*J.flag & 2)) ? 2 : 0, ncv = !(mo <= thr) ? 4 : 0;
+        const int lg = mo > 0.0 && thr > 0.0 ? (int)fmin(99.0, fmax(-99.0, 10.0 * log10(mo / thr))) : -99;
+        J.counters[0] = 0; J.counters[1] = (J.iters & 0xff) | (nrank << 8); J.counters[2] = 0; J.counters[3] = rej | ncv | ((lg + 100) << 8);
+        if (bad && J.err) atomicOr(J.err, 2);
+    }
+}
+// dst_a <- src_a (and dst_b <- src_b) unless bit 1 of *err is set: the Newton chain only replaces the stored bases when it converged,
+// so that the host can repeat a missed step on the regular chain from the SAME warm start
+struct VgCopyIfArgs { const int* err[2]; const double* src_a[2]; double* dst_a[2]; const double* src_b[2]; double* dst_b[2]; long n[2]; int njobs; };
+__global__ void vg_copy_if_kernel(const VgCopyIfArgs a) {
+    const int k = blockIdx.y;
+    if (k >= a.njobs || (*a.err[k] & 2)) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (long)gridDim.x * blockDim.x) {
+        if (a.dst_b[k]) a.dst_b[k][i] = a.src_b[k][i];          // (b first: a may overwrite b's source)
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (long)gridDim.x * blockDim.x) a.dst_a[k][i] = a.src_a[k][i];
+}
+hipError_t vg_copy_if_launch(const int* const* err, const double* const* src_a, double* const* dst_a, const double* const* src_b,
+                             double* const* dst_b, const long* n, int njobs, hipStream_t st) {
+    VgCopyIfArgs a;
+    a.njobs = njobs;
+    for (int k = 0; k < njobs; ++k) { a.err[k] = err[k]; a.src_a[k] = src_a[k]; a.dst_a[k] = dst_a[k]; a.src_b[k] = src_b[k]; a.dst_b[k] = dst_b[k]; a.n[k] = n[k]; }
+    hipLaunchKernelGGL(vg_copy_if_kernel, dim3(64, njobs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t vg_newton_check_launch(const VgNewtonCheckJob* jobs, int njobs, hipStream_t st) {
+    if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
+    VgNewtonCheckArgs a;
+    a.njobs = njobs;
+    for (int j = 0; j < njobs; ++j) { a.job[j] = jobs[j]; if (jobs[j].m < 1 || jobs[j].m > 256) return hipErrorInvalidValue; }
+    hipLaunchKernelGGL(vg_newton_check_kernel, dim3(njobs), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 

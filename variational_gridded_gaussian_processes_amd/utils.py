@@ -1,11 +1,12 @@
-"""Host-side helpers around the fit / predict path: evaluation metrics, scalers and the gridding of a
-reference field into cell integrals.  Plain torch / numpy on the host -- none of this is on the hot path.
+"""Host-side helpers around the fit / predict path: the two predictive metrics the reference's notebook
+61 imports but does not ship, and the gridding of a reference field into cell integrals.  Plain torch / numpy on the host -- none
+of this is on the hot path.  (The reference's point metrics and scalers -- evaluationmetrics.py, dataprocessors.py -- are out of
+scope, SURVEY.md section 2 rows 8-9: use the reference's own.)
 
 Array-based: the reference's loaders wrap xarray datasets read from netCDF files (src/utils/dataloaders.py); neither xarray nor
-the files exist here, so the functions take the arrays those loaders would hand over.  The four point metrics and the scalers
-mirror src/utils/evaluationmetrics.py:6-58 and src/utils/dataprocessors.py:3-72 (same names, arguments, 2-D requirement);
-nlpd / msll are the two metrics SURVEY.md lists as missing from the reference (standard definitions, Rasmussen & Williams
-section 2.5).  grid_cells mirrors GulfStream.grid_ref_data_simpson / grid_ref_data_trapz (dataloaders.py:485-539)."""
+the files exist here, so the functions take the arrays those loaders would hand over.  nlpd / msll: standard definitions
+(Rasmussen & Williams section 2.5).  grid_cells mirrors GulfStream.grid_ref_data_simpson / grid_ref_data_trapz
+(dataloaders.py:485-539).  The synthetic track generator (generate_track's array-level twin) lives in datagen.py."""
 from __future__ import annotations
 
 import math
@@ -23,27 +24,6 @@ def _pair(true: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
     return true - pred
 
 
-def mean_squared_error(true: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
-    """evaluationmetrics.py:6-16."""
-    return _pair(true, pred).square().mean()
-
-
-def mean_absolute_error(true: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
-    """evaluationmetrics.py:18-28."""
-    return _pair(true, pred).abs().mean()
-
-
-def root_mean_squared_error(true: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
-    """evaluationmetrics.py:30-40."""
-    return mean_squared_error(true, pred).sqrt()
-
-
-def r_squared(true: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
-    """evaluationmetrics.py:42-58: 1 - RSS / TSS."""
-    res = _pair(true, pred)
-    return 1.0 - res.square().sum() / (true - true.mean()).square().sum()
-
-
 def nlpd(true: torch.Tensor, mean: torch.Tensor, var: torch.Tensor) -> torch.Tensor:
     """Negative log predictive density of Gaussian marginals, averaged over the points: mean_i [ (y_i - m_i)^2 / (2 v_i) +
     log(2 pi v_i) / 2 ].  var is the predictive variance INCLUDING the observation noise when `true` is noisy."""
@@ -57,26 +37,6 @@ def msll(true: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, train_target
     variance (negative = better than trivial)."""
     mu0, v0 = train_targets.mean(), train_targets.var(unbiased=False)
     return nlpd(true, mean, var) - nlpd(true, torch.full_like(mean, float(mu0)), torch.full_like(var, float(v0)))
-
-
-# ---- scalers (dataprocessors.py:3-72) ------------------------------------------------------------------------------------------
-def min_max_scaling(tensor: torch.Tensor, min=None, max=None):
-    lo = tensor.min() if min is None else min
-    hi = tensor.max() if max is None else max
-    return (tensor - lo) / (hi - lo), lo, hi
-
-
-def min_max_inverse(tensor: torch.Tensor, min, max) -> torch.Tensor:
-    return tensor * (max - min) + min
-
-
-def z_scaling(tensor: torch.Tensor):
-    mu, sd = tensor.mean(), tensor.std()          # (torch.std: unbiased, as in the reference)
-    return (tensor - mu) / sd, mu, sd
-
-
-def z_inverse(tensor: torch.Tensor, mean, std) -> torch.Tensor:
-    return tensor * std + mean
 
 
 # ---- reference field -> cell integrals (what q_v() of the Gridded* models is compared with) -------------------------------------
