@@ -28,6 +28,7 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 #include "ctx.h"
 #include "factor_elem.h"
 #define VG_CHOL_MAXJOBS_HOST 8
+#define VG_SP_SLABS 4             // split-K slabs of the early projection S' = [A2;dA2] Y (riding in the Cholesky launch)
 #define VG_NEWTON_TOL 1e-12      // off-diagonal threshold of the Newton chain's rotations, relative to ||Gw||_F / m
 #define VG_NEWTON_NOISE 1e-13    // diagonal entries below this fraction of the largest are "at the rounding floor" (VgRefineJob::noise)
 #define VG_NEWTON_ACCEPT 1e-11   // ... of its convergence check: Gw = S G S^T comes out of two GEMMs with ~ eps sqrt(m) ||G|| of rounding noise per
@@ -282,6 +283,7 @@ static void layout(vggp_ctx* c, Bump& b) {
     static const char* ste = getenv("VGGP_ST_TARGET");
     c->st_split = pick_split(st_tiles, (int)n2, ste ? atoi(ste) : 256);
     c->St = b.take<double>((size_t)c->st_split * 2 * m2 * n1);
+    c->Sp = b.take<double>((size_t)VG_SP_SLABS * 2 * m2 * n1);       // [A2;dA2] Y of the thin chain's early projection (split-K slabs)
     const int cc_tiles = (int)(((2 * m1 + 63) / 64) * ((m2 + 63) / 64));
     const char* cce = getenv("VGGP_CC_TARGET");
     c->cc_split = pick_split(cc_tiles, (int)n1, cce ? atoi(cce) : 64);
@@ -328,7 +330,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     c->sub_next = false; c->sub_mode = false; c->sub_r_cap[0] = c->sub_r_cap[1] = 0;
     c->pred_consumed = false;
     c->acc_valid = false; c->last_warm = false; c->last_slabs = false; c->last_payload = nullptr;
-    c->last_thin = false; c->thin_off = false;
+    c->last_thin = false; c->thin_off = false; c->thin_block = 0;
     c->cur_newton = 0; c->last_newton = false; c->newton_next = false; c->newton_block = 0; c->newton_iters = 3;
     c->desc = *desc;
     c->d[0] = VgDim();
@@ -503,7 +505,13 @@ static int vg_chol_big_enqueue(vggp_ctx* c, const int* dims, int ndims, hipStrea
     return VGGP_OK;
 }
 
-int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap, bool fused, bool apply_ns) {
+int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap, bool fused, bool apply_ns,
+                        bool early) {
+    // early (thin chain of a fused single-rank step, finish_enqueue): the pass over Y is taken BEFORE the whitening --
+    // S' = [A2;dA2] Y needs nothing but the factor build, so it rides in the Cholesky launch (250 idle CUs for 43 us), and
+    // S = L2^-1 S' is a handful of extra strips of the substitution launch (L^-1 (A Y) instead of (L^-1 A) Y: the same
+    // substitution, applied to other right-hand sides).  [C;C1;C2] is then complete before the Ritz solve and nothing that touches
+    // Y or C is left behind it.
     const long n1 = c->desc.n1, n2 = c->desc.n2, m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
     hipStream_t sx = vg_side(c, st);
@@ -549,8 +557,24 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         }
     static const bool chol_big_off = getenv("VGGP_NO_CHOL_BIG") != nullptr;
     const bool any_big = (d1.m > VG_TRSM_BLK || d2.m > VG_TRSM_BLK) && !chol_legacy && !chol_big_off;
+    VgGemmBatch gsp;
+    vg_gemm_init(&gsp);
+    int sp_slabs = 1;
+    if (early) {
+        if (!(dinv_path && !any_big && !ns_on_chol && fused && !reduce && Y && (vg_ride(c) || c->prof) && sx == st)) {
+            vg_set_error("internal: the early projection was requested where it cannot run");
+            return VGGP_ESTATE;
+        }
+        vg_gemm_add(&gsp, d2.AD, n2, 1, Y, n1, 1, c->Sp, (int)n1, (int)(2 * m2), (int)n1, (int)n2, VG_SP_SLABS, 2L * m2 * n1);
+        sp_slabs = gsp.p[0].ksplit;
+        if (c->prof) {                 // profiling mode: every launch group by itself -- the pass over Y as a launch of its own
+            vg_gemm_xcd_group(&gsp, 0);
+            VG_HIP(vg_gemm_launch(&gsp, st, VG_GEMM_TAG_GRAM_PROJECT));
+            VG_MARK(4);
+        }
+    }
     if (!any_big) {
-        VG_HIP(vg_chol_launch(cj, 2, st, ns_on_chol ? &gns : nullptr));
+        VG_HIP(vg_chol_launch(cj, 2, st, (early && !c->prof) ? &gsp : (ns_on_chol ? &gns : nullptr)));
     } else {
         // a factor beyond one 128-block: blocked (vg_chol_big_enqueue); a small partner keeps the one-launch MFMA kernel.  Either
         // way the launch leaves L0 and the diagonal-block inverses only; L0^-1 comes out of the substitution below.
@@ -571,7 +595,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     {
         const bool big = d1.m > VG_TRSM_BLK || d2.m > VG_TRSM_BLK;
         if (!big) {
-            VgTrsmJob tj[8];
+            VgTrsmJob tj[16];
             int nt = 0;
             for (int k = 0; k < 2; ++k) {
                 VgDim& d = c->d[k];
@@ -586,6 +610,12 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
                     tj[nt++].rhs_ident = 1;
                 }
             }
+            if (early)               // S = L2^-1 S', slab by slab (the substitution is linear: the consumer sums the slabs)
+                for (int sl = 0; sl < sp_slabs; ++sl)
+                    for (int b = 0; b < 2; ++b) {
+                        const long o = (long)sl * 2 * m2 * n1 + (long)b * m2 * n1;
+                        tj[nt++] = VgTrsmJob{d2.L0, d2.Dinv0, c->Sp + o, c->St + o, m2, 256, 16, n1, 1, n1, 1, n1, (int)m2, 0};
+                    }
             VG_HIP(vg_trsm_launch(tj, nt, st));
         } else {
             // 128 < m <= 256: blocked (128-row diagonal solves + one GEMM update between them), in place on copies
@@ -633,7 +663,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     VgGemmBatch gp, gc;
     vg_gemm_init(&gp);
     vg_gemm_add(&gp, d2.BV, n2, 1, Y, n1, 1, c->St, (int)n1, (int)(2 * m2), (int)n1, (int)n2, c->st_split, 2L * m2 * n1);
-    const int st_slabs = gp.p[0].ksplit;
+    const int st_slabs = early ? sp_slabs : gp.p[0].ksplit;
     vg_gemm_xcd_group(&gp, 0);
     // predicted start basis of this step's eigensolvers: the previous step's tail left Qpred (Ep), 1.5 Qpred (Fp) and
     // W = Qpred Qpred^T (Wp); the Newton-Schulz step Fp += -0.5 W Qpred rides in this launch (see the tail of finish_enqueue)
@@ -645,7 +675,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
                 vg_gemm_add(b, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
             }
     };
-    if (!ride) {
+    if (!ride && !early) {
         add_ns(&gp);
         VG_HIP(vg_gemm_launch(&gp, sp, VG_GEMM_TAG_GRAM_PROJECT));
         if (sp == st) VG_MARK(4);
@@ -673,7 +703,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         add_gram(&g);
         add_ns(&g);
         VG_HIP(vg_gemm_launch(&g, st));
-        c->ride_proj = gp; c->ride_cc = gc; c->ride_pending = true;
+        c->ride_proj = gp; c->ride_cc = gc; c->ride_pending = !early;      // (early: S exists already, finish_enqueue places [C;C1;C2] itself)
     } else {
         if (sp == st) add_gram(&gc);
         VG_HIP(vg_gemm_launch(&gc, sp));
@@ -709,7 +739,7 @@ static bool vg_sub_ident() { static const bool ex = getenv("VGGP_SUB_EXTRAP") !=
 
 static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, bool warm, hipStream_t st, bool copy_theta,
                           bool from_slabs = false, bool extrap = false, bool refine = false, bool subspace = false, bool thin = false,
-                          int newton = 0) {
+                          int newton = 0, bool thin_early = false) {
     // stand-alone finish (multi-rank seam): refresh the device copy of the hyper-parameters; inside a fused step the
     // factor kernel already did
     if (copy_theta) VG_HIP(hipMemcpyAsync(c->theta, c->h_theta, 6 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -739,6 +769,10 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         // annihilates every null component); V1 = orth(Z) spans range(G); Rayleigh-Ritz on V1 G V1^T gives the range eigenpairs
         // (W, theta) -- and that is all the ELBO and its gradient need: every rotated quantity is W (V1 . V1^T) W^T of an
         // r x r matrix, formed by the tail kernel itself.  No complement basis, no full eigensolve, no m x m rotation.
+        // early (vg_partials_enqueue took the pass over Y before the whitening: S is there): [C;C1;C2] rides beside the row QR,
+        // {C,C1,C2} V1_2^T joins the launch after it, V1_1 (.) rides in the Ritz launch, the tail kernel follows the Ritz solve directly
+        // and the new range basis E_r = W V1 -- which only the NEXT step reads -- trails behind the tail (the host has its results by then)
+        const bool early = thin_early && from_slabs && !ride;
         const double* Gr[2] = {G0[0], G0[1]};
         int grn[2] = {ghn[0], ghn[1]};
         double* gdst[2] = {d1.GH, c->payload};
@@ -757,7 +791,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             if (from_slabs && ghn[k] > 1) { Gr[k] = gdst[k]; grn[k] = 1; Hr[k] = gdst[k] + (long)c->d[k].m * c->d[k].m; hrn[k] = 1; }
         VgRowQrJob qj[2];
         for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; qj[k] = VgRowQrJob{d.TM, d.V1s, d.sub_r, d.m, nullptr, nullptr, 0}; }
-        VG_HIP(vg_rowqr_launch(qj, 2, st, ride ? &c->ride_proj : nullptr));      // + rider: S = [B2;V2] Y
+        // + rider: [C;C1;C2] (early; profiling mode has launched it by itself) / S = [B2;V2] Y
+        VG_HIP(vg_rowqr_launch(qj, 2, st, early ? (c->prof ? nullptr : &c->ride_cc) : (ride ? &c->ride_proj : nullptr)));
         if (ride) ride_stage = 1;
         VG_MARK(9);
         vg_gemm_init(&g);
@@ -767,6 +802,10 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_add(&g, d.V1s, d.m, 1, Gr[k], d.m, 1, d.Zs, d.m, r, d.m, d.m, 1, 0, grn[k], ghs[k]);        // T = V1 G
             vg_gemm_add(&g, d.V1s, d.m, 1, d.Mk, d.m, 1, d.tMV, d.m, r, d.m, d.m);                              // V1 Mk0
             vg_gemm_add(&g, d.V1s, d.m, 1, Hr[k], d.m, 1, d.tHV, d.m, r, d.m, d.m, 1, 0, hrn[k], ghs[k]);       // V1 H0
+        }
+        if (early) {
+            const int ic = vg_gemm_add(&g, C3, m2, 1, d2.V1s, 1, m2, c->tCV, d2.sub_r, (int)(3 * m1), d2.sub_r, (int)m2);   // {C,C1,C2} V1_2^T
+            g.p[ic].a_nslab = ccn; g.p[ic].a_slab = ccs;
         }
         VG_HIP(vg_gemm_launch(&g, st));
         VG_MARK(10);
@@ -780,6 +819,10 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
             vg_gemm_add(&gx, d.tMV, d.m, 1, d.V1s, 1, d.m, d.tAM, r, r, r, d.m);                                // V1 Mk0 V1^T
             vg_gemm_add(&gx, d.tHV, d.m, 1, d.V1s, 1, d.m, d.tAH, r, r, r, d.m);                                // V1 H0 V1^T
         }
+        if (early)
+            for (int q = 0; q < 3; ++q)                                                                         // V1_1 ({C,C1,C2} V1_2^T)
+                vg_gemm_add(&gx, d1.V1s, m1, 1, c->tCV + (long)q * m1 * d2.sub_r, d2.sub_r, 1, c->tAC + (long)q * d1.sub_r * d2.sub_r,
+                            d2.sub_r, d1.sub_r, d2.sub_r, (int)m1);
         VgEigJob sj[2];
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
@@ -796,7 +839,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         VG_MARK(11);
         const int ac_nslab = 1;
         const long ac_slab = 3L * d1.sub_r * d2.sub_r;
-        {
+        if (!early) {
             // {C, C1, C2} V1_2^T, and the new range basis E_r = W V1 into the leading rows of QtPrev (next step's V)
             vg_gemm_init(&g);
             {
@@ -831,6 +874,14 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 #endif
         VG_HIP(vg_thin_tail_launch(&tt, st));
         VG_MARK(18);
+        if (early) {           // E_r = W V1 -> leading rows of QtPrev: behind the tail, whose pinned result block the host polls
+            vg_gemm_init(&g);
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                vg_gemm_add(&g, d.Ws, d.sub_r, 1, d.V1s, d.m, 1, d.QtPrev, d.m, d.sub_r, d.m, d.sub_r);
+            }
+            VG_HIP(vg_gemm_launch(&g, st));
+        }
         return VGGP_OK;
     }
     if (warm && subspace) {
@@ -1258,7 +1309,7 @@ struct VgStart { bool extrap, refine, subspace, thin; int newton; };
 // read-outs re-run the finish half cold on the resident G, H, C), and no caller that wanted the full m-space state of a warm step.
 static bool vg_thin_ok(const vggp_ctx* c, bool own_payload) {
     static const bool off = getenv("VGGP_NO_THIN") != nullptr;
-    if (off || c->thin_off || !own_payload || !c->desc.warm_start || (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) || !c->sub_next) return false;
+    if (off || c->thin_off || c->thin_block > 0 || !own_payload || !c->desc.warm_start || (c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) || !c->sub_next) return false;
     for (int k = 0; k < 2; ++k) {
         const VgDim& d = c->d[k];
         if (!d.have_prev || !d.tMV || d.sub_r < 1 || d.sub_r > VG_THIN_MAXR || d.sub_r > d.thin_rows) return false;
@@ -1453,6 +1504,7 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     }
     if (status == VG_ESUBMISS) {            // (the caller repeats the step; the warm start was reset above)
         c->sub_next = false;
+        if (c->cur_thin) c->thin_block = 32;      // the directions the thin chain leaves out mattered: full chains for a while
         return VG_ESUBMISS;
     }
     if (status == VGGP_ENOTPD) { vg_set_error("a Kuu factor is not positive definite after jitter 1e-6"); return VGGP_ENOTPD; }
@@ -1463,6 +1515,7 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
         c->d[k].thin_rows = c->cur_thin ? c->cur_r[k] : c->d[k].m;      // ... all of it, or the range rows of a thin step
     }
     c->last_thin = c->cur_thin;
+    if (c->thin_block > 0) --c->thin_block;
     // (the Newton chain keeps the eigenpairs in the order of its start basis, the eigensolver sorts: after a crossing the two stored
     //  bases of a chain switch may not correspond row by row -- the extrapolated start is then poor, the chain that receives it
     //  notices: the regular one sweeps, the Newton chain misses and the step is repeated)
@@ -1612,10 +1665,17 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         return finish_collect(c, elbo_out, grad_out, info, st);
     }
     const VgGraphKey key{Y, c->payload, yy_total};
+    // thin chain with the early projection (vg_partials_enqueue): where the step defers its projection launches to the eigensolver
+    // chain anyway, and both factors are single 128-blocks
+    static const bool no_early = getenv("VGGP_NO_EARLY") != nullptr;
+    static const bool no_ride = getenv("VGGP_NO_RIDE") != nullptr;
+    const bool thin_early = thin && !no_early && !no_ride && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st &&
+                            getenv("VGGP_CHOL_LEGACY") == nullptr;
     rc = run_graph(c, warm ? (thin ? VG_G_STEP_WARM_T : newton ? VG_G_STEP_WARM_N : subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
                             : VG_G_STEP_COLD, key, st, [&] {
-        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns);
-        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace, thin, newton);
+        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns, thin_early);
+        return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace, thin, newton,
+                                        thin_early);
     }, extrap && !apply_ns);
     if (rc) return rc;
     if (extrap) c->pred_consumed = true;

@@ -277,6 +277,7 @@ hipError_t vg_dstage_launch(const VgMspace* ms, hipStream_t st);
 // "Thin" m-space stage of a subspace-start step (thin.hip): everything from the Ritz pairs to the pinned result block in ONE
 // single-workgroup kernel, range directions only (r1, r2 <= 32); all inputs at unit outputscale.
 #define VG_THIN_MAXR 32
+#define VG_THIN_ELBO_TOL 1e-10 // ... and its first-order effect on the bound, relative to the number of observations
 #define VG_THIN_MISS 1e-12     // admissible (tr G - sum of the Ritz values) per complement direction, relative to lam_max
 struct VgThinTail {
     const double* theta;             // device [6]: ell1, ell2, s1, s2, v, sequence number

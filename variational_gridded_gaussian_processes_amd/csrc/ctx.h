@@ -49,6 +49,7 @@ struct vggp_ctx {
     void* arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
     // cross-dimension buffers
+    double* Sp = nullptr;             // [A2;dA2] Y (split-K slabs): the early projection of the thin chain
     double *St = nullptr, *CCslab = nullptr, *payload = nullptr, *GH1 = nullptr;
     double *T3 = nullptr, *P3 = nullptr, *beta = nullptr, *bl2 = nullptr, *bl1 = nullptr, *invD = nullptr;
     double *rowpart = nullptr, *r1 = nullptr, *r1l = nullptr, *r2 = nullptr, *r2l = nullptr, *dotpart = nullptr, *ol = nullptr;
@@ -102,6 +103,7 @@ struct vggp_ctx {
     int newton_block = 0;             // steps for which the Newton chain stays off after a miss
     int newton_iters = 3, newton_cap = 0;
     bool last_thin = false;           // the last finished step ran the thin chain: QtPrev holds r rows, the m-space state (beta, 1/D, E, F) is not there
+    int thin_block = 0;               // steps for which the thin chain stays off after it missed
     bool thin_off = false;            // a caller needed the full m-space state of a warm step (vggp_zgrad): keep to the full chain from now on
     bool sub_mode = false;            // the current step uses the subspace start (U then holds the identity)         // the last step ended in the polish in both dimensions: refine the next start basis
     // the context's collective (comm.hip)
@@ -137,7 +139,7 @@ int vg_comm_wait(vggp_ctx* c, hipStream_t st);
 struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };
 int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st);
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false, bool fused = false,
-                        bool apply_ns = false);
+                        bool apply_ns = false, bool early = false);
 void vg_masked_free(vggp_ctx* c);
 // batch of triangular solves, each in place on its X (api.hip trsm_batch: element (row k, column c) at X[k * sk + c * sc])
 #define VG_TRSM_BLK 128

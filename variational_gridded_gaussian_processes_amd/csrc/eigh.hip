@@ -1619,15 +1619,19 @@ size_t vg_eigh_log_bytes(int m) {
 // Classical Gram-Schmidt with re-orthogonalisation, row by row, everything in LDS: the k dot products of a row are taken
 // by the 16 waves in parallel, then 128 lanes subtract; a third pass when a pass removed most of the row.
 struct VgRowQrArgs { VgRowQrJob job[2]; int njobs; };
-// NE: elements of a row per lane in the in-block pass of wave 0 (2: m <= 128, 4: m <= 256)
-template <int NE>
+// NE: elements of a row per lane in the in-block pass of wave 0 (2: m <= 128, 4: m <= 256); CP: with the pass-through copy (its 16
+// registers per lane live across the whole row loop: the m > 128 instance, which only the thin chain uses, goes without -- with it
+// the kernel spilled 66 VGPRs and the m <= 128 instance paid 6 us for it)
+template <int NE, bool CP>
 __device__ __forceinline__ void vg_rowqr_body(const VgRowQrJob& J, double* V) {
     const int r = J.r, m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the pass-through copy: loads now (registers), stores after the last row -- a global store inside the row loop would be
     // waited for at every barrier (__syncthreads drains vmcnt)
-    double cpv[16];
+    double cpv[CP ? 16 : 1];
+    if (CP) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; cpv[u] = i < J.cp_n ? J.cp_src[i] : 0.0; }
+        for (int u = 0; u < (CP ? 16 : 1); ++u) { const long i = tid + u * 1024L; cpv[u] = i < J.cp_n ? J.cp_src[i] : 0.0; }
+    }
     for (int i = tid; i < r * m; i += 1024) V[i] = J.Z[i];
     __syncthreads();
     // Block Gram-Schmidt, 4 rows at a time (r is a multiple of 4): the block is projected off all finished rows twice
@@ -1728,21 +1732,26 @@ __device__ __forceinline__ void vg_rowqr_body(const VgRowQrJob& J, double* V) {
         __syncthreads();
     }
     for (int i = tid; i < r * m; i += 1024) J.V1[i] = V[i];
+    if (CP) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { const long i = tid + u * 1024L; if (i < J.cp_n) J.cp_dst[i] = cpv[u]; }
-    for (long i = tid + 16 * 1024L; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];      // (m <= 128: never taken)
+        for (int u = 0; u < (CP ? 16 : 1); ++u) { const long i = tid + u * 1024L; if (i < J.cp_n) J.cp_dst[i] = cpv[u]; }
+        for (long i = tid + 16 * 1024L; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];      // (m <= 128: never taken)
+    } else {
+        for (long i = tid; i < J.cp_n; i += 1024) J.cp_dst[i] = J.cp_src[i];
+    }
 }
-__global__ __launch_bounds__(1024) void vg_rowqr_kernel(const VgRowQrArgs a, const VgGemmBatch rider) {
+// (two kernels, not one with a branch: the register allocation of a kernel is the maximum over its paths)
+template <int NE, bool CP>
+__global__ __launch_bounds__(1024) void vg_rowqr_kernel_t(const VgRowQrArgs a, const VgGemmBatch rider) {
     extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
     if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
         if (threadIdx.x >= 512) return;
         vg_gemm_body<64, 16, 512>(rider, vq_dyn, blockIdx.x - a.njobs);
         return;
     }
-    const VgRowQrJob& J = a.job[blockIdx.x];
-    if (J.m <= 128) vg_rowqr_body<2>(J, vq_dyn);
-    else vg_rowqr_body<4>(J, vq_dyn);
+    vg_rowqr_body<NE, CP>(a.job[blockIdx.x], vq_dyn);
 }
+
 
 static const size_t VG_RIDER_LDS = 2 * VgTile<64, 16>::TILE * sizeof(double);
 
@@ -1760,7 +1769,14 @@ hipError_t vg_rowqr_launch(const VgRowQrJob* jobs, int njobs, hipStream_t st, co
         const size_t need = (size_t)jobs[j].r * jobs[j].m * sizeof(double);
         if (need > lds) lds = need;
     }
-    hipLaunchKernelGGL(vg_rowqr_kernel, dim3(njobs + rb.total_tiles), dim3(1024), lds, st, a, rb);
+    // (separate kernels, not branches: a kernel's register allocation is the maximum over its paths -- the pass-through copy holds
+    //  32 registers per lane across the whole row loop, which only the full subspace chain needs)
+    bool wide = false, copy = false;
+    for (int j = 0; j < njobs; ++j) { wide = wide || jobs[j].m > 128; copy = copy || jobs[j].cp_n > 0; }
+    const dim3 grid(njobs + rb.total_tiles), blk(1024);
+    if (wide) hipLaunchKernelGGL((vg_rowqr_kernel_t<4, false>), grid, blk, lds, st, a, rb);
+    else if (copy) hipLaunchKernelGGL((vg_rowqr_kernel_t<2, true>), grid, blk, lds, st, a, rb);
+    else hipLaunchKernelGGL((vg_rowqr_kernel_t<2, false>), grid, blk, lds, st, a, rb);
     return hipGetLastError();
 }
 
@@ -1996,7 +2012,11 @@ hipError_t vg_eigh_setup() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_refine_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_rowqr_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vg_rowqr_kernel_t<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vg_rowqr_kernel_t<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vg_rowqr_kernel_t<4, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);      // r x m <= 64 x 256 doubles
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_eigh_kernel),

@@ -284,7 +284,11 @@ __global__ __launch_bounds__(1024) void vg_thin_tail_kernel(const VgThinTail tt)
             // (S[14], S[18] are sums of the SCALED Ritz values: compare with the scaled trace)
             const double lmax = k ? l2s[0] : l1s[0], trG = k ? sl2 : sl1, sth = k ? S[18] : S[14];
             const int nrank = (int)(k ? S[20] : S[19]);
-            const bool miss = !(fabs(trG - sth) <= VG_THIN_MISS * lmax * (double)(m - r + 1));
+            // ... and small enough for the BOUND: to first order the directions left out would add (tr G_d - sum theta_d) tr G_other / v
+            // to sum log D -- negligible on the headline (1e-16 lam_max eigenvalues), not where the spectrum decays slowly into the
+            // cut (m_d = 24 after a jump: 3e-4 of an ELBO of 1.8e4, found by test_rbf_warm_chain_at_small_inducing_counts)
+            const double first_order = fabs(trG - sth) * (k ? sl1 : sl2) * iv;
+            const bool miss = !(fabs(trG - sth) <= VG_THIN_MISS * lmax * (double)(m - r + 1)) || !(first_order <= VG_THIN_ELBO_TOL * N);
             const int s0 = st_s[k][0], s1w = st_s[k][1], rstat = rc_s[k][2];
             ired[k * 4 + 0] = rc_s[k][0];                        // rotation rounds of the Ritz solve (0 on the Newton path)
             ired[k * 4 + 1] = (rc_s[k][1] & 0xff) | (nrank << 8);
