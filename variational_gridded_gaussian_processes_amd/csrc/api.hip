@@ -867,6 +867,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         tt.ac_nslab = ac_nslab; tt.ac_slab = ac_slab;
         tt.G1 = Gr[0]; tt.H1 = Hr[0]; tt.G2 = Gr[1]; tt.H2 = Hr[1];
         tt.out = c->out; tt.hout = c->d_hout;
+        tt.beta_out = c->beta; tt.invd_out = c->invD;
         tt.peer_fail = (payload == c->payload && (c->n_ranks > 1 || c->comm || c->cb)) ? c->payload + c->payload_len : nullptr;
         for (int k = 0; k < 2; ++k) { tt.jit[k] = c->d[k].jitter; tt.status[k] = c->d[k].status; tt.rcounters[k] = c->d[k].counters2; }
 #ifdef VGGP_DIAG
@@ -1731,6 +1732,59 @@ static int vg_accurate_state(vggp_ctx* c, hipStream_t st) {
     return VGGP_OK;
 }
 
+// Read-outs straight from a THIN step (no cold recompute): beta and 1/D - 1 vanish outside range x range, so
+//   q(v) mean      = R1r (beta sqrt(s1 s2) / v) R2r^T,                              R_dr = L0_d E_r^T  (m_d x r_d: range columns only)
+//   q(v) variance  = s1 s2 [ rowsq(L0_1) rowsq(L0_2)^T + (R1r o R1r)(1/D - 1)(R2r o R2r)^T ]   (sum over ALL directions of R^2 = diag L0 L0^T)
+//   posterior(x*)  = the full formulas with t_d = E_r L0_d^-1 a_d(x*)  (r_d x n*)
+// and the range eigenpairs of a thin step are exact Ritz pairs of G on span(V1) = range(G) -- consistent (eigenvalue, eigenvector)
+// pairs, unlike the projected-off complement rows of the full warm chain whose mixtures made the cold recompute necessary
+// (DESIGN.md section 2).  VGGP_NO_THIN_READOUT=1: recompute cold as after any warm step.
+static bool vg_thin_readout(const vggp_ctx* c) {
+    static const bool off = getenv("VGGP_NO_THIN_READOUT") != nullptr;
+    return !off && c->have_step && c->last_thin && !c->acc_valid;
+}
+__global__ void vg_rowsq_kernel(const double* L, int m, double* out) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    double s = 0.0;
+    for (int k = 0; k <= a; ++k) s += L[(long)a * m + k] * L[(long)a * m + k];
+    out[a] = s;
+}
+__global__ void vg_add_outer_kernel(double* x, const double* u, const double* v, int m1, int m2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)m1 * m2) x[i] += u[i / m2] * v[i % m2];
+}
+static int vg_qv_thin(vggp_ctx* c, double* mean, double* var, hipStream_t st) {
+    const long m1 = c->desc.m1, m2 = c->desc.m2;
+    VgDim &d1 = c->d[0], &d2 = c->d[1];
+    const int r1 = d1.thin_rows, r2 = d2.thin_rows;
+    VgGemmBatch g;
+    vg_gemm_init(&g);
+    for (int k = 0; k < 2; ++k) {
+        VgDim& d = c->d[k];
+        vg_gemm_add(&g, d.L0, d.m, 1, d.QtPrev, 1, d.m, d.RQ, d.thin_rows, d.m, d.thin_rows, d.m);           // L0 E_r^T  (m x r)
+    }
+    VG_HIP(vg_gemm_launch(&g, st));
+    for (int k = 0; k < 2; ++k) VG_HIP(vg_scale_sq_launch(c->d[k].RQ, c->d[k].RQsq, (long)c->d[k].m * c->d[k].thin_rows, st));
+    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, (long)r1 * r2, st, vg_uexp(d1.basis), vg_uexp(d2.basis)));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, d1.RQ, r1, 1, c->wq, r2, 1, c->T3, r2, (int)m1, r2, r1);
+    vg_gemm_add(&g, d1.RQsq, r1, 1, c->wq + (long)r1 * r2, r2, 1, c->T3 + m1 * m2, r2, (int)m1, r2, r1);
+    VG_HIP(vg_gemm_launch(&g, st));
+    vg_gemm_init(&g);
+    vg_gemm_add(&g, c->T3, r2, 1, d2.RQ, 1, r2, mean, (int)m2, (int)m1, (int)m2, r2);
+    vg_gemm_add(&g, c->T3 + m1 * m2, r2, 1, d2.RQsq, 1, r2, var, (int)m2, (int)m1, (int)m2, r2);
+    VG_HIP(vg_gemm_launch(&g, st));
+    double* rs1 = c->rowpart;            // (m1 * 8 doubles of scratch, free outside a step)
+    double* rs2 = c->r2;                 // (2 * m2)
+    hipLaunchKernelGGL(vg_rowsq_kernel, dim3((unsigned)((m1 + 127) / 128)), dim3(128), 0, st, d1.L0, (int)m1, rs1);
+    hipLaunchKernelGGL(vg_rowsq_kernel, dim3((unsigned)((m2 + 127) / 128)), dim3(128), 0, st, d2.L0, (int)m2, rs2);
+    hipLaunchKernelGGL(vg_add_outer_kernel, dim3((unsigned)((m1 * m2 + 255) / 256)), dim3(256), 0, st, var, rs1, rs2, (int)m1, (int)m2);
+    VG_HIP(hipGetLastError());
+    VG_HIP(vg_scale_launch(var, m1 * m2, c->theta, 0, st, vg_uexp(d1.basis), vg_uexp(d2.basis)));
+    return VGGP_OK;
+}
+
 static int build_RQ(vggp_ctx* c, hipStream_t st) {
     VgGemmBatch g;
     vg_gemm_init(&g);
@@ -1750,6 +1804,7 @@ extern "C" int vggp_qv(vggp_ctx* c, double* mean, double* var, void* stream) {
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const long m1 = c->desc.m1, m2 = c->desc.m2;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
+    if (vg_thin_readout(c)) return vg_qv_thin(c, mean, var, st);
     int rc = vg_accurate_state(c, st);
     if (rc) return rc;
     if ((rc = build_RQ(c, st))) return rc;
@@ -1819,8 +1874,11 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
     if (ns == 0) return VGGP_OK;
     // per chunk: A(m x c), T(m x c) for both dims, T2sq, U, Uv (m1 x c); once: W_d = Q_d^T L0_d^-1 (m x m)
     const size_t per = (size_t)chunk * (2 * m1 + 3 * m2 + 2 * m1) + (size_t)(m1 * m1 + m2 * m2);
-    int rc = vg_accurate_state(c, st);
+    // after a thin step: the same formulas on the range directions only (q1 x q2 instead of m1 x m2), no cold recompute
+    const bool thin_ro = vg_thin_readout(c);
+    int rc = thin_ro ? VGGP_OK : vg_accurate_state(c, st);
     if (rc) return rc;
+    const int q1 = thin_ro ? c->d[0].thin_rows : (int)m1, q2 = thin_ro ? c->d[1].thin_rows : (int)m2;
     if ((rc = vg_ensure_misc(c, per * sizeof(double)))) return rc;
     double* p = (double*)c->misc;
     double* A1 = p; p += m1 * chunk;
@@ -1833,12 +1891,12 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
     double* W1 = p; p += m1 * m1;
     double* W2 = p;
     VgDim &d1 = c->d[0], &d2 = c->d[1];
-    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, m1 * m2, st));   // wq = [beta rs / v | invD - 1]
+    VG_HIP(vg_qv_weights_launch(c->theta, c->beta, c->invD, c->wq, (long)q1 * q2, st));   // wq = [beta rs / v | invD - 1]  (q1 x q2, compact)
     {
         VgGemmBatch g;                                                              // whitening and rotation in one operand
         vg_gemm_init(&g);
-        vg_gemm_add(&g, d1.QtPrev, m1, 1, d1.Linv0, m1, 1, W1, (int)m1, (int)m1, (int)m1, (int)m1);
-        vg_gemm_add(&g, d2.QtPrev, m2, 1, d2.Linv0, m2, 1, W2, (int)m2, (int)m2, (int)m2, (int)m2);
+        vg_gemm_add(&g, d1.QtPrev, m1, 1, d1.Linv0, m1, 1, W1, (int)m1, q1, (int)m1, (int)m1);
+        vg_gemm_add(&g, d2.QtPrev, m2, 1, d2.Linv0, m2, 1, W2, (int)m2, q2, (int)m2, (int)m2);
         VG_HIP(vg_gemm_launch(&g, st));
     }
     for (long off = 0; off < ns; off += chunk) {
@@ -1849,15 +1907,15 @@ extern "C" int vggp_posterior(vggp_ctx* c, const double* xs1, const double* xs2,
         VG_HIP(vg_factor_build_launch(fj, 2, c->theta, st));
         VgGemmBatch g;
         vg_gemm_init(&g);
-        vg_gemm_add(&g, W1, m1, 1, A1, cn, 1, T1, cn, (int)m1, cn, (int)m1);
-        vg_gemm_add(&g, W2, m2, 1, A2, cn, 1, T2, cn, (int)m2, cn, (int)m2);
+        vg_gemm_add(&g, W1, m1, 1, A1, cn, 1, T1, cn, q1, cn, (int)m1);
+        vg_gemm_add(&g, W2, m2, 1, A2, cn, 1, T2, cn, q2, cn, (int)m2);
         VG_HIP(vg_gemm_launch(&g, st));
-        VG_HIP(vg_scale_sq_launch(T2, T2sq, (long)m2 * cn, st));
+        VG_HIP(vg_scale_sq_launch(T2, T2sq, (long)q2 * cn, st));
         vg_gemm_init(&g);
-        vg_gemm_add(&g, c->wq, m2, 1, T2, cn, 1, U, cn, (int)m1, cn, (int)m2);
-        vg_gemm_add(&g, c->wq + m1 * m2, m2, 1, T2sq, cn, 1, Uv, cn, (int)m1, cn, (int)m2);
+        vg_gemm_add(&g, c->wq, q2, 1, T2, cn, 1, U, cn, q1, cn, q2);
+        vg_gemm_add(&g, c->wq + (long)q1 * q2, q2, 1, T2sq, cn, 1, Uv, cn, q1, cn, q2);
         VG_HIP(vg_gemm_launch(&g, st));
-        VG_HIP(vg_post_combine_launch(c->theta, T1, U, Uv, nullptr, (int)m1, (int)m2, cn, mean + off, var + off, st));
+        VG_HIP(vg_post_combine_launch(c->theta, T1, U, Uv, nullptr, q1, q2, cn, mean + off, var + off, st));
     }
     return VGGP_OK;
 }

@@ -290,6 +290,7 @@ struct VgThinTail {
     int ac_nslab; long ac_slab;
     const double *G1, *H1, *G2, *H2; // [m][m] reduced Gram pairs (only their diagonals are read: traces over ALL directions)
     double* out;                     // device [8] (may be null)
+    double *beta_out, *invd_out;     // [r1][r2] (compact): beta and 1/D on range x range, for the read-outs (may be null)
     VgHostOut* hout;                 // pinned result block
     const double* peer_fail;         // see VgMspace
     const double* jit[2];

@@ -174,6 +174,10 @@ __global__ __launch_bounds__(1024) void vg_thin_tail_kernel(const VgThinTail tt)
             b = P * iD; bl2 = b * l2; bl1 = b * l1; w = -a * iD;          // w = 1/D - 1
             S[0] += log1p(a); S[1] += P * b; S[2] += b * b; S[3] += a * iD; S[4] += b * b * (2.0 + a); S[5] += b * P1; S[6] += b * P2;
         }
+        if (tt.beta_out && i < r1 && j < r2) {                   // the range block of beta and 1/D: all q(v) / posterior(x*) need of the step
+            tt.beta_out[i * r2 + j] = b;
+            tt.invd_out[i * r2 + j] = 1.0 + w;
+        }
         base[B_T0 * sz + i * ld + j] = b; base[B_T1 * sz + j * ld + i] = b;
         base[B_T2 * sz + i * ld + j] = bl2; base[B_T3 * sz + i * ld + j] = bl1;
         base[B_W2T * sz + i * ld + j] = w;
