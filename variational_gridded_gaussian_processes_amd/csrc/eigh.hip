@@ -1745,6 +1745,9 @@ template <int NE, bool CP>
 __global__ __launch_bounds__(1024) void vg_rowqr_kernel_t(const VgRowQrArgs a, const VgGemmBatch rider) {
     extern __shared__ __attribute__((aligned(16))) double vq_dyn[];
     if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
+        // (the upper 8 waves leave before the body's barriers: on gfx9 -- this library is built for gfx950 only, vggp_create
+        //  refuses anything else -- s_barrier counts the waves of the workgroup that have not terminated, so the remaining 8
+        //  synchronise among themselves; HIP's portable model does not promise that)
         if (threadIdx.x >= 512) return;
         vg_gemm_body<64, 16, 512>(rider, vq_dyn, blockIdx.x - a.njobs);
         return;

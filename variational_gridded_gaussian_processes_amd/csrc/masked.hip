@@ -260,6 +260,18 @@ static int vgm_prepare(vggp_ctx* c, bool iter = false) {
     size_t off = 0;
     vgm_layout(*w, nullptr, off);
     w->bytes = off + 4096;
+    {   // say what does not fit instead of failing inside hipMalloc (the scattered / masked assemblies are not chunked over N)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && w->bytes > free_b) {
+            vg_set_error("the dense M-space workspace of this %s step needs %.1f GiB (M = %ld, n1 = %ld, n2 = %ld, m1 = %ld, m2 = %ld; "
+                         "~10 M^2 + (m1^2 + m2^2) N doubles) but only %.1f GiB of device memory are free%s",
+                         sc ? "scattered" : "masked", (double)w->bytes / 1073741824.0, (long)(m1 * m2), (long)c->desc.n1, (long)c->desc.n2,
+                         (long)m1, (long)m2, (double)free_b / 1073741824.0,
+                         (sc || iter) ? "" : "; vggp_elbo_step_masked_iter needs no M x M matrix");
+            w->M = 0;
+            return VGGP_ENOMEM;
+        }
+    }
     VG_HIP(hipMalloc(&w->mem, w->bytes));
     VG_HIP(hipMemset(w->mem, 0, w->bytes));
     off = 0;

@@ -784,15 +784,30 @@ class GriddedMatern12SVGP(_GriddedReadout, KroneckerStructure):
         return MultivariateNormal(qu.mean[idx], qu.variance[idx])
 
 
-def _detect_cartesian(Z: torch.Tensor):
+def _cluster_coordinates(v: np.ndarray, rtol: float):
+    """Distinct values of v up to rtol * span(v) (coordinates that went through a float32 round trip or a scaler differ in the
+    last bits): (centres, index of each entry's centre); a centre is the mean of its cluster."""
+    order = np.argsort(v, kind="stable")
+    vs = v[order]
+    tol = rtol * max(float(vs[-1] - vs[0]), np.finfo(np.float64).tiny) if len(vs) else 0.0
+    new = np.concatenate([[True], np.diff(vs) > tol]) if len(vs) else np.zeros(0, bool)
+    gid = np.cumsum(new) - 1
+    centres = np.bincount(gid, weights=vs) / np.bincount(gid)
+    inv = np.empty(len(v), dtype=np.int64)
+    inv[order] = gid
+    return centres, inv
+
+
+def _detect_cartesian(Z: torch.Tensor, rtol: float = 1e-6):
     """Z (M, 2) listing every pair of cartesian_prod(z1, z2) exactly once, in any row order -> (z1, z2, u_of_row) with
-    u_of_row[r] = i1 * m2 + i2, the engine's inducing index of row r; raises when Z is not such a grid."""
-    Zn = Z.detach().cpu().numpy()
+    u_of_row[r] = i1 * m2 + i2, the engine's inducing index of row r; raises when Z is not such a grid.  Coordinates are
+    matched up to rtol of their span, so a grid that passed through float32 or a scaler is still recognised."""
+    Zn = Z.detach().cpu().numpy().astype(np.float64)
     if Zn.ndim != 2 or Zn.shape[1] != 2:
         raise ValueError("Z must be (M, 2)")
-    z1, i1 = np.unique(Zn[:, 0], return_inverse=True)
-    z2, i2 = np.unique(Zn[:, 1], return_inverse=True)
-    u = i1.astype(np.int64) * len(z2) + i2.astype(np.int64)
+    z1, i1 = _cluster_coordinates(Zn[:, 0], rtol)
+    z2, i2 = _cluster_coordinates(Zn[:, 1], rtol)
+    u = i1 * len(z2) + i2
     if len(z1) * len(z2) != Zn.shape[0] or len(np.unique(u)) != Zn.shape[0]:
         raise ValueError("GriddedMatern12SVGP: Z must be a full cartesian grid cartesian_prod(z1, z2): only then is "
                          "k(Z, Z) = kron(K1, K2) (arbitrary scattered inducing points are out of scope)")
