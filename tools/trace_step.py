@@ -2,7 +2,14 @@
 start offsets, durations and the idle gaps between consecutive kernels.  usage: trace_step.py <dir>"""
 import csv, glob, os, sys
 f = sys.argv[1] if sys.argv[1].endswith(".csv") else glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("vg_")]
+rows = []
+for r in csv.DictReader(open(f)):
+    nm = r["Kernel_Name"]
+    if nm.startswith("void "):            # template instantiations are recorded with their return type
+        nm = nm[5:]
+    if nm.startswith("vg_"):
+        r["Kernel_Name"] = nm
+        rows.append(r)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts with vg_factor_kernel; take the median-length step among the last 50
 starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("vg_factor_kernel")]

@@ -123,7 +123,7 @@ extern "C" int vggp_destroy(vggp_ctx* c) {
     VgDeviceGuard guard;
     (void)guard.enter(c->device);
     (void)vg_quiesce(c);
-    for (int i = 0; i < 16; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    for (int i = 0; i < 20; ++i) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
     for (int i = 0; i < VG_MAXEV; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < VG_NFORK; ++i) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
@@ -561,7 +561,11 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
     vg_gemm_init(&gsp);
     int sp_slabs = 1;
     if (early) {
-        if (!(dinv_path && !any_big && !ns_on_chol && fused && !reduce && Y && (vg_ride(c) || c->prof) && sx == st)) {
+        // (two callers: the fused single-rank step -- no reduction, [C;C1;C2] becomes a rider of the eigensolver chain -- and the
+        //  partials half of a multi-rank step -- reduce: [C;C1;C2] shares the Gram launch and the slab reduction fills the payload)
+        const bool ok_fused = fused && !reduce && (vg_ride(c) || c->prof);
+        const bool ok_partials = !fused && reduce;
+        if (!(dinv_path && !any_big && !ns_on_chol && (ok_fused || ok_partials) && Y && sx == st)) {
             vg_set_error("internal: the early projection was requested where it cannot run");
             return VGGP_ESTATE;
         }
@@ -772,7 +776,9 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         // early (vg_partials_enqueue took the pass over Y before the whitening: S is there): [C;C1;C2] rides beside the row QR,
         // {C,C1,C2} V1_2^T joins the launch after it, V1_1 (.) rides in the Ritz launch, the tail kernel follows the Ritz solve directly
         // and the new range basis E_r = W V1 -- which only the NEXT step reads -- trails behind the tail (the host has its results by then)
-        const bool early = thin_early && from_slabs && !ride;
+        // (multi-rank step: the partials half took the early pass and [C;C1;C2] arrives reduced in the payload -- same placement,
+        //  no rider beside the row QR)
+        const bool early = thin_early && !ride;
         const double* Gr[2] = {G0[0], G0[1]};
         int grn[2] = {ghn[0], ghn[1]};
         double* gdst[2] = {d1.GH, c->payload};
@@ -792,7 +798,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         VgRowQrJob qj[2];
         for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; qj[k] = VgRowQrJob{d.TM, d.V1s, d.sub_r, d.m, nullptr, nullptr, 0}; }
         // + rider: [C;C1;C2] (early; profiling mode has launched it by itself) / S = [B2;V2] Y
-        VG_HIP(vg_rowqr_launch(qj, 2, st, early ? (c->prof ? nullptr : &c->ride_cc) : (ride ? &c->ride_proj : nullptr)));
+        VG_HIP(vg_rowqr_launch(qj, 2, st, early ? ((c->prof || !from_slabs) ? nullptr : &c->ride_cc) : (ride ? &c->ride_proj : nullptr)));
         if (ride) ride_stage = 1;
         VG_MARK(9);
         vg_gemm_init(&g);
@@ -1257,8 +1263,8 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
        VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_FINISH_WARM_T, VG_G_STEP_WARM_T,
-       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_COUNT };
-static_assert(VG_G_COUNT <= 16, "vggp_ctx::gexec");
+       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_PARTIALS_E, VG_G_FINISH_WARM_TE, VG_G_COUNT };
+static_assert(VG_G_COUNT <= 20, "vggp_ctx::gexec");
 // _T: thin chain (subspace start without a complement basis, thin.hip); _N: Newton chain
 // _S: subspace start (see finish_enqueue)
 // _X: warm start from the extrapolated basis; _XR: ... refined to first order before the eigensolver (see finish_enqueue)
@@ -1346,7 +1352,7 @@ static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out
     out->refine = warm && !out->subspace && !out->newton && vg_refine(c, out->extrap);
     c->sub_mode = out->subspace;
     if (out->subspace && (c->sub_r_cap[0] != c->d[0].sub_r || c->sub_r_cap[1] != c->d[1].sub_r)) {
-        for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S, (int)VG_G_FINISH_WARM_T, (int)VG_G_STEP_WARM_T})
+        for (int v : {(int)VG_G_FINISH_WARM_S, (int)VG_G_STEP_WARM_S, (int)VG_G_FINISH_WARM_T, (int)VG_G_STEP_WARM_T, (int)VG_G_FINISH_WARM_TE})
             if (c->gexec[v]) { (void)vg_quiesce(c); (void)hipGraphExecDestroy(c->gexec[v]); c->gexec[v] = nullptr; c->gkey[v] = VgGraphKey(); }
         c->sub_r_cap[0] = c->d[0].sub_r; c->sub_r_cap[1] = c->d[1].sub_r;
     }
@@ -1630,8 +1636,13 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         // -> finish graph; the one host synchronisation is in finish_collect.  Every rank finishes redundantly, so all ranks
         // hold the identical value and gradient without a broadcast.
         const VgGraphKey kp{Y, c->payload, 0.0}, kf{nullptr, c->payload, yy_total};
-        rc = run_graph(c, extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, kp, st,
-                       [&] { return vg_partials_enqueue(c, Y, c->payload, st, true, extrap, false, apply_ns); }, extrap && !apply_ns);
+        // thin chain: the pass over the rank's slab of Y rides beside the Cholesky (vg_partials_enqueue, early), the finish half places
+        // the small products of the reduced [C;C1;C2] as the fused single-rank step does
+        static const bool no_early_mr = getenv("VGGP_NO_EARLY") != nullptr;
+        const bool thin_early = thin && !no_early_mr && !extrap && !c->prof && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st &&
+                                getenv("VGGP_CHOL_LEGACY") == nullptr;
+        rc = run_graph(c, thin_early ? VG_G_PARTIALS_E : extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, kp, st,
+                       [&] { return vg_partials_enqueue(c, Y, c->payload, st, true, extrap, false, apply_ns, thin_early); }, extrap && !apply_ns);
         {
             // fault injection for the failure-path test (tests/test_gpu_dist.py): VGGP_FAULT_PARTIALS_AT=<step number>
             static const long fault_at = [] { const char* e = getenv("VGGP_FAULT_PARTIALS_AT"); return e ? atol(e) : -1L; }();
@@ -1658,9 +1669,9 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         if (extrap) c->pred_consumed = true;
         c->have_partials = true;
         if ((rc = vg_allreduce(c, c->payload, c->payload_len + 1, st))) return rc;
-        rc = run_graph(c, warm ? (thin ? VG_G_FINISH_WARM_T : newton ? VG_G_FINISH_WARM_N : subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
+        rc = run_graph(c, warm ? (thin ? (thin_early ? VG_G_FINISH_WARM_TE : VG_G_FINISH_WARM_T) : newton ? VG_G_FINISH_WARM_N : subspace ? VG_G_FINISH_WARM_S : extrap ? (refine ? VG_G_FINISH_WARM_XR : VG_G_FINISH_WARM_X) : VG_G_FINISH_WARM)
                                 : VG_G_FINISH_COLD, kf, st,
-                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace, thin, newton); });
+                       [&] { return finish_enqueue(c, c->payload, yy_total, warm, st, false, false, extrap, refine, subspace, thin, newton, thin_early); });
         if (rc) return rc;
         c->last_warm = warm; c->last_slabs = false; c->last_payload = c->payload; c->last_yy = yy_total;
         return finish_collect(c, elbo_out, grad_out, info, st);

@@ -81,8 +81,8 @@ struct vggp_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork[VG_NFORK] = {}, ev_join[VG_NFORK] = {};
     bool use_graph = true;
-    hipGraphExec_t gexec[16] = {};
-    VgGraphKey gkey[16];
+    hipGraphExec_t gexec[20] = {};
+    VgGraphKey gkey[20];
     // what the accurate (cold) recompute of the read-outs needs from the last step (api.hip vg_accurate_state)
     bool last_warm = false, last_slabs = false, acc_valid = false;
     const double* last_payload = nullptr;
