@@ -565,6 +565,32 @@ def test_rbf_warm_chain_at_small_inducing_counts(engine, m):
         assert any(sum(o[3]["rounds"]) == 0 for o in out[6:15]), [o[3]["rounds"] for o in out[6:15]]
 
 
+@pytest.mark.parametrize("n1,n2,m1,m2", [(2048, 96, 64, 48), (96, 35, 88, 80), (1536, 200, 128, 40)])
+def test_thin_chain_on_slab_shapes(engine, n1, n2, m1, m2):
+    """Wide / short slabs (the shape of a rank's shard): here the plan's split of S = [B2;V2] Y has FEWER slabs than the early
+    projection S' = [A2;dA2] Y leaves behind (its own split is fixed), so the slabs of S must have room of their own -- a step on
+    such a shape once wrote S past its buffer into S'.  Warm RBF trajectory against the oracle."""
+    X, y, x1, x2 = D.gen_grid(n1, n2)
+    del X
+    g1, g2 = np.linspace(0, 1, m1), np.linspace(0, 1, m2)
+    engine.plan("rbf", "points", g1, x1, "rbf", "points", g2, x2, warm_start=True)
+    Y = torch.tensor(y.reshape(n2, n1), device=DEV)
+    yy = engine.sumsq(Y)
+    f1, f2 = Kr.Factor("points", "rbf", g1, x1), Kr.Factor("points", "rbf", g2, x2)
+    quiet = 0
+    for k in range(12):
+        th = np.array([0.2, 0.3, 1.0, 0.8, 0.01]) * (1.0 + 0.01 * k)
+        elbo, grad, info = engine.elbo_step(Y, yy, th)
+        quiet += sum(info["rounds"]) == 0
+        if k in (0, 3, 6, 9, 11):
+            ref = Kr.elbo_step(y.reshape(n2, n1), f1, f2, th)
+            # (5e-8 / 3e-7: the accuracy of the early projection on ill-conditioned factors, see
+            #  test_rbf_warm_chain_at_small_inducing_counts; measured 1.3e-8 at 2048 x 96, m = 64 / 48)
+            assert abs(elbo - ref.elbo) <= 5e-8 * max(abs(ref.elbo), 0.5 * n1 * n2), (k, info)
+            assert rel(grad, ref.grad) < 3e-7, (k, info)
+    assert quiet >= 6          # the warm chain was taken
+
+
 def test_riders_and_graph_equal_plain_launches(engine):
     """Profiling mode runs every launch group by itself on one stream (no graph replay, no riders): the same trajectory must
     give the same numbers as the default mode, to rounding of the reduction orders that differ (none should)."""

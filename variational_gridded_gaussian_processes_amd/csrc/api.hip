@@ -282,7 +282,7 @@ static void layout(vggp_ctx* c, Bump& b) {
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
     static const char* ste = getenv("VGGP_ST_TARGET");
     c->st_split = pick_split(st_tiles, (int)n2, ste ? atoi(ste) : 256);
-    c->St = b.take<double>((size_t)c->st_split * 2 * m2 * n1);
+    c->St = b.take<double>((size_t)std::max(c->st_split, VG_SP_SLABS) * 2 * m2 * n1);   // (the early projection leaves up to VG_SP_SLABS slabs of S here)
     c->Sp = b.take<double>((size_t)VG_SP_SLABS * 2 * m2 * n1);       // [A2;dA2] Y of the thin chain's early projection (split-K slabs)
     const int cc_tiles = (int)(((2 * m1 + 63) / 64) * ((m2 + 63) / 64));
     const char* cce = getenv("VGGP_CC_TARGET");
