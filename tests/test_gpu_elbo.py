@@ -512,6 +512,44 @@ def test_readouts_after_warm_rbf_steps_have_cold_accuracy(engine):
             assert rel(pm.cpu().numpy(), om) < 1e-6 and rel(pv.cpu().numpy(), ov) < 1e-5
 
 
+@pytest.mark.parametrize("n,m,warm_plan", [(512, 128, False), (384, 96, True), (256, 192, False)])
+def test_cold_rbf_steps_take_the_range_finder(engine, n, m, warm_plan):
+    """A COLD step of an RBF plan (first step, warm start off, a jump) does not run the full Jacobi solve: pivoted-Cholesky range
+    finder + thin chain (vg_cold_thin_prepass).  Value, gradient, q(v), posterior and the inducing-point gradient (which rebuilds the
+    full state) against the oracle; a spectrum that does not fit the 32 rows (short lengthscale) must fall back to the full solve
+    and still be right."""
+    X, y, x1, x2 = D.gen_grid(n, n)
+    del X
+    g = np.linspace(0, 1, m)
+    f1, f2 = Kr.Factor("points", "rbf", g, x1), Kr.Factor("points", "rbf", g, x2)
+    engine.plan("rbf", "points", g, x1, "rbf", "points", g, x2, warm_start=warm_plan)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    yy = engine.sumsq(Y)
+    xs = np.random.default_rng(8).uniform(0, 1, (200, 2))
+    for k, ell in enumerate((0.2, 0.26, 0.15)):                # 30 % / 40 % apart: each one a cold step in a warm plan as well
+        th = np.array([ell, 1.1 * ell, 1.0, 0.9, 0.01])
+        elbo, grad, info = engine.elbo_step(Y, yy, th)
+        ref = Kr.elbo_step(y.reshape(n, n), f1, f2, th)
+        assert sum(info["rounds"]) < 400, info                 # (the full solve of two 128 x 128 matrices: ~1900 rounds)
+        assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, info)
+        assert rel(grad, ref.grad) < RTOL, (k, info)
+        mean, var = engine.qv()
+        rm, rv = Kr.q_v(ref)
+        assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-6
+        pm, pv = engine.posterior(torch.tensor(xs, device=DEV))
+        om, ov = Kr.posterior(ref, f1, f2, xs)
+        assert rel(pm.cpu().numpy(), om) < 1e-6 and rel(pv.cpu().numpy(), ov) < 1e-5
+    # a spectrum beyond 32 directions: refused by the miss check, repeated with the full solve
+    th = np.array([0.03, 0.035, 1.0, 0.9, 0.01])
+    elbo, grad, info = engine.elbo_step(Y, yy, th)
+    ref = Kr.elbo_step(y.reshape(n, n), f1, f2, th)
+    # (1e-6 / 3e-4: ~60 range directions whose K0-eigenvalues pass through the jitter level -- the regime is ill-conditioned for every
+    #  path: the ORACLE's analytic d/d ell and its own central differences agree to 3e-5 here, the full cold solve with the range
+    #  finder switched off differs from the oracle by 2e-7 / 9e-5 at 384 x 384, m = 96; this assertion is about the fall-back working)
+    assert abs(elbo - ref.elbo) <= 1e-6 * abs(ref.elbo) and rel(grad, ref.grad) < 3e-4, info
+    assert sum(info["rounds"]) > 400, info
+
+
 def _rbf_trajectory(engine, profile, steps=26, m=64):
     """A smooth 1 %-per-step path with one 30 % jump: subspace start, Newton Ritz solve, riders -- and their fall-backs."""
     n = 192
@@ -565,7 +603,7 @@ def test_rbf_warm_chain_at_small_inducing_counts(engine, m):
         assert any(sum(o[3]["rounds"]) == 0 for o in out[6:15]), [o[3]["rounds"] for o in out[6:15]]
 
 
-@pytest.mark.parametrize("n1,n2,m1,m2", [(2048, 96, 64, 48), (96, 35, 88, 80), (1536, 200, 128, 40)])
+@pytest.mark.parametrize("n1,n2,m1,m2", [(2048, 96, 64, 48), (96, 35, 88, 80), (1536, 200, 128, 64)])
 def test_thin_chain_on_slab_shapes(engine, n1, n2, m1, m2):
     """Wide / short slabs (the shape of a rank's shard): here the plan's split of S = [B2;V2] Y has FEWER slabs than the early
     projection S' = [A2;dA2] Y leaves behind (its own split is fixed), so the slabs of S must have room of their own -- a step on

@@ -277,6 +277,7 @@ static void layout(vggp_ctx* c, Bump& b) {
             d.Zs = b.take<double>(m * m); d.V1s = b.take<double>(m * m); d.Hs = b.take<double>(m * m); d.Ws = b.take<double>(m * m);
             d.tMV = b.take<double>(VG_THIN_MAXR * m); d.tHV = b.take<double>(VG_THIN_MAXR * m);
             d.tAM = b.take<double>(VG_THIN_MAXR * VG_THIN_MAXR); d.tAH = b.take<double>(VG_THIN_MAXR * VG_THIN_MAXR);
+            d.Omega = b.take<double>(VG_THIN_MAXR * m);
         }
     }
     const int st_tiles = (int)(((2 * m2 + 63) / 64) * ((n1 + 63) / 64));
@@ -363,6 +364,19 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
         }
     }
     for (int k = 0; k < 2; ++k) VG_HIP(vg_identity_launch(c->d[k].Id, c->d[k].m, nullptr));
+    for (int k = 0; k < 2; ++k) {          // start rows of the cold range finder (vg_cold_thin_prepass): fixed pseudo-random numbers in (-1, 1)
+        VgDim& d = c->d[k];
+        if (!d.Omega) continue;
+        std::vector<double> om((size_t)VG_THIN_MAXR * d.m);
+        unsigned long long z = 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1);
+        for (double& v : om) {
+            z += 0x9E3779B97F4A7C15ull;                          // splitmix64
+            unsigned long long x = z;
+            x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+            v = (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        }
+        VG_HIP(hipMemcpy(d.Omega, om.data(), sizeof(double) * om.size(), hipMemcpyHostToDevice));
+    }
     VG_HIP(hipDeviceSynchronize());
     c->desc.x1 = c->desc.x2 = c->desc.grid1 = c->desc.grid2 = nullptr;   // host pointers not retained
     c->have_partials = c->have_step = c->have_masked = false;
@@ -564,7 +578,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         // (two callers: the fused single-rank step -- no reduction, [C;C1;C2] becomes a rider of the eigensolver chain -- and the
         //  partials half of a multi-rank step -- reduce: [C;C1;C2] shares the Gram launch and the slab reduction fills the payload)
         const bool ok_fused = fused && !reduce && (vg_ride(c) || c->prof);
-        const bool ok_partials = !fused && reduce;
+        const bool ok_partials = reduce;                 // (also the cold thin step: fused, reduced operands)
         if (!(dinv_path && !any_big && !ns_on_chol && (ok_fused || ok_partials) && Y && sx == st)) {
             vg_set_error("internal: the early projection was requested where it cannot run");
             return VGGP_ESTATE;
@@ -1263,7 +1277,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
        VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_FINISH_WARM_T, VG_G_STEP_WARM_T,
-       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_PARTIALS_E, VG_G_FINISH_WARM_TE, VG_G_COUNT };
+       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_PARTIALS_E, VG_G_FINISH_WARM_TE, VG_G_STEP_COLD_T, VG_G_COUNT };
 static_assert(VG_G_COUNT <= 20, "vggp_ctx::gexec");
 // _T: thin chain (subspace start without a complement basis, thin.hip); _N: Newton chain
 // _S: subspace start (see finish_enqueue)
@@ -1389,9 +1403,15 @@ static int vg_quiesce(vggp_ctx* c) {
 }
 static int vg_wait_step(vggp_ctx* c, hipStream_t st) {
     static const bool nopoll = getenv("VGGP_NO_POLL") != nullptr;
-    if (nopoll || c->prof || c->comm || c->cb || c->n_ranks > 1) { c->poll_stream_valid = false; return vg_comm_wait(c, st); }
     const volatile double* seq = &c->h_out->seq;
     const double want = c->h_theta[5];
+    if (nopoll || c->prof || (c->n_ranks > 1 && !c->comm && !c->cb)) { c->poll_stream_valid = false; return vg_comm_wait(c, st); }
+    if (c->comm && !c->cb) {
+        // RCCL transport: the same word, polled together with the communicator's health (a dead peer is an error, not a hang)
+        const int wrc = vg_comm_wait(c, st, seq, want);
+        c->poll_stream = st; c->poll_stream_valid = (wrc == VGGP_OK);
+        return wrc;
+    }
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (long spin = 0;; ++spin) {
@@ -1596,6 +1616,37 @@ static int elbo_finish_once(vggp_ctx* c, const double* payload, double yy_total,
     return finish_collect(c, elbo_out, grad_out, info, st);
 }
 
+// ---- cold start of the thin chain (RBF factors): a range finder instead of the full Jacobi solve.
+// G = B B^T of an RBF factor has numerical rank ~17 of 128, and "Z = V G" maps ANY r-row start V onto range(G) exactly (G annihilates
+// the null components) -- but the row-by-row orthonormalisation of Z keeps the small range directions only when the rows of V are
+// GRADED (row i mostly within the i leading eigen-directions); a random sketch is not.  So:
+//   pass 1:  r0 = 32 steps of diagonally pivoted Cholesky of G (thin.hip, vg_pivchol_kernel): graded columns spanning range(G),
+//            orthonormalised in pivot order into the leading rows of QtPrev;
+//   pass 2:  the warm thin chain itself from those rows;
+// and the tail kernel's miss check (tr G - sum theta) decides as in every thin step: a spectrum that does not fit 32 rows is refused,
+// the step is repeated with the full solve and the thin chain stays off for 32 steps.  VGGP_NO_COLD_THIN=1: always the full solve.
+#define VG_COLD_THIN_R 32
+static bool vg_cold_thin_ok(const vggp_ctx* c) {
+    static const bool off = getenv("VGGP_NO_COLD_THIN") != nullptr || getenv("VGGP_NO_THIN") != nullptr || getenv("VGGP_NO_SUBSPACE") != nullptr;
+    if (off || c->thin_off || c->thin_block > 0 || c->prof || (c->desc.flags & (VGGP_FLAG_BLOCK_JACOBI | VGGP_FLAG_SCATTERED))) return false;
+    if (c->n_ranks > 1 || c->comm || c->cb) return false;
+    for (int k = 0; k < 2; ++k) {
+        const VgDim& d = c->d[k];
+        if (!d.Omega || !d.tMV || d.kind != VGGP_KIND_RBF || d.m < 3 * VG_COLD_THIN_R || d.m > 256) return false;
+    }
+    return true;
+}
+static int vg_cold_thin_prepass(vggp_ctx* c, const double* payload, hipStream_t st) {
+    const double* Gk[2] = {c->d[0].GH, payload};                  // reduced Gram matrices (the partials half ran with reduce)
+    VgPivCholJob pj[2];
+    for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; pj[k] = VgPivCholJob{Gk[k], d.Omega, d.TM, d.m, VG_COLD_THIN_R}; }
+    VG_HIP(vg_pivchol_launch(pj, 2, st));
+    VgRowQrJob qj[2];
+    for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; qj[k] = VgRowQrJob{d.TM, d.QtPrev, VG_COLD_THIN_R, d.m, nullptr, nullptr, 0}; }
+    VG_HIP(vg_rowqr_launch(qj, 2, st, nullptr));
+    return VGGP_OK;
+}
+
 static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const double theta[5], double* elbo_out,
                           double grad_out[5], vggp_info* info, void* stream);
 // A step whose subspace start turns out to have missed part of the range (VG_ESUBMISS: the hyper-parameters jumped) is repeated
@@ -1681,6 +1732,26 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
     // chain anyway, and both factors are single 128-blocks
     static const bool no_early = getenv("VGGP_NO_EARLY") != nullptr;
     static const bool no_ride = getenv("VGGP_NO_RIDE") != nullptr;
+    if (!warm && vg_cold_thin_ok(c)) {
+        // cold step of a rank-deficient plan: range finder + thin chain (see vg_cold_thin_prepass) instead of the full Jacobi solve
+        const bool early = !no_early && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st && getenv("VGGP_CHOL_LEGACY") == nullptr;
+        const int keep[2] = {c->d[0].sub_r, c->d[1].sub_r};
+        c->d[0].sub_r = c->d[1].sub_r = VG_COLD_THIN_R;          // (sizes of the captured thin chain; the host's rank bookkeeping keeps its own)
+        rc = run_graph(c, VG_G_STEP_COLD_T, key, st, [&] {
+            int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/true, false, /*fused=*/true, false, early);
+            if (!r1) r1 = vg_cold_thin_prepass(c, c->payload, st);
+            return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, /*warm=*/true, st, false, /*from_slabs=*/false, false, false, /*subspace=*/true,
+                                            /*thin=*/true, 0, early);
+        });
+        c->d[0].sub_r = keep[0]; c->d[1].sub_r = keep[1];
+        if (rc) return rc;
+        c->cur_thin = true; c->cur_extrap = false; c->cur_newton = 0;
+        c->cur_r[0] = c->cur_r[1] = VG_COLD_THIN_R;
+        c->have_partials = true;
+        c->last_warm = true;             // (no full m-space state behind this step: the read-outs that need one rebuild it)
+        c->last_slabs = false; c->last_payload = c->payload; c->last_yy = yy_total;
+        return finish_collect(c, elbo_out, grad_out, info, st);
+    }
     const bool thin_early = thin && !no_early && !no_ride && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st &&
                             getenv("VGGP_CHOL_LEGACY") == nullptr;
     rc = run_graph(c, warm ? (thin ? VG_G_STEP_WARM_T : newton ? VG_G_STEP_WARM_N : subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)

@@ -109,16 +109,28 @@ void vg_comm_abort(vggp_ctx* c) {
 // blocks for ever when a peer died before its ncclAllReduce; here the stream is polled together with the communicator's
 // asynchronous error state, and after VGGP_COMM_TIMEOUT_S seconds (default 120) without completion the communicator is
 // aborted and the step returns VGGP_ERCCL.  Single-rank contexts and the callback transport use the plain synchronisation.
-int vg_comm_wait(vggp_ctx* c, hipStream_t st) {
+// seq / want: when given, completion is the arrival of the step's sequence number in the pinned result block (the last word the
+// step's last kernel writes) instead of the stream running empty -- the same test the single-rank step polls (api.hip, vg_wait_step).
+int vg_comm_wait(vggp_ctx* c, hipStream_t st, const volatile double* seq, double want) {
     if (!c->comm || !g_rccl.CommGetAsyncError) { VG_HIP(hipStreamSynchronize(st)); return VGGP_OK; }
     static const double limit_s = [] { const char* e = getenv("VGGP_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (long spin = 0;; ++spin) {
-        const hipError_t q = hipStreamQuery(st);
-        if (q == hipSuccess) return VGGP_OK;
-        if (q != hipErrorNotReady) { vg_set_error("hipStreamQuery -> %s", hipGetErrorString(q)); vg_comm_abort(c); return VGGP_EHIP; }
-        if ((spin & 1023) == 1023) {            // every ~1000 polls: the communicator's health and the clock
+        if (seq) {
+            if (*seq == want) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return VGGP_OK; }
+            __builtin_ia32_pause();
+        } else {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return VGGP_OK;
+            if (q != hipErrorNotReady) { vg_set_error("hipStreamQuery -> %s", hipGetErrorString(q)); vg_comm_abort(c); return VGGP_EHIP; }
+        }
+        if ((spin & (seq ? 16383 : 1023)) == (seq ? 16383 : 1023)) {            // every so many polls: the communicator's health and the clock
+            if (seq) {                           // a fault on the stream would leave the word unwritten for ever
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) { if (*seq == want) return VGGP_OK; vg_set_error("the step's stream ran empty without its result block"); return VGGP_ESTATE; }
+                if (q != hipErrorNotReady) { vg_set_error("hipStreamQuery -> %s", hipGetErrorString(q)); vg_comm_abort(c); return VGGP_EHIP; }
+            }
             ncclResult_t ae = ncclSuccess;
             if (g_rccl.CommGetAsyncError(reinterpret_cast<ncclComm_t>(c->comm), &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
                 vg_set_error("RCCL reports an asynchronous error on rank %d / %d: %s (communicator aborted)", c->rank, c->n_ranks,

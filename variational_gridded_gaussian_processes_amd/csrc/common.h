@@ -299,6 +299,10 @@ struct VgThinTail {
     unsigned long long* stamps = nullptr;   // diagnostic builds (-DVGGP_DIAG): s_memrealtime stamps of the kernel's phases
 };
 hipError_t vg_thin_tail_launch(const VgThinTail* tt, hipStream_t st);
+// cold range finder (thin.hip): r steps of diagonally pivoted Cholesky of G (m x m, m <= 256); the columns become the rows of V (r x m)
+struct VgPivCholJob { const double* G; const double* Omega; double* V; int m; int r; };
+struct VgPivCholArgs { VgPivCholJob job[2]; };
+hipError_t vg_pivchol_launch(const VgPivCholJob* jobs, int njobs, hipStream_t st);
 hipError_t vg_thin_tail_setup();
 hipError_t vg_final_launch(const VgMspace* ms, hipStream_t st);
 // inducing-point gradient (vggp_zgrad): weights of the gradient functional, and the row contraction with d kappa / d z

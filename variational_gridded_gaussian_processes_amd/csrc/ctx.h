@@ -28,6 +28,7 @@ struct VgDim {
     int sub_r = 0;                    // rows treated as the numerical range in the next step (0: subspace start off)
     // thin chain (thin.hip): V1 Mk0, V1 H0 (r x m) and V1 Mk0 V1^T, V1 H0 V1^T (r x r)
     double *tMV = nullptr, *tHV = nullptr, *tAM = nullptr, *tAH = nullptr;
+    double* Omega = nullptr;          // [VG_THIN_MAXR][m] fixed pseudo-random rows: start of the thin chain's cold range finder
     int thin_rows = 0;                // leading rows of QtPrev that hold eigenvectors (m after a full solve, r after a thin step)
     bool have_prev = false, have_prev2 = false;     // QtPrev / QtPrev2 hold the bases of the last / the step before
 };
@@ -133,7 +134,7 @@ int vg_comm_init(vggp_ctx* c, int n_ranks, int rank, const void* unique_id);
 void vg_comm_destroy(vggp_ctx* c);
 int vg_allreduce(vggp_ctx* c, double* buf, long count, hipStream_t st);
 void vg_comm_abort(vggp_ctx* c);
-int vg_comm_wait(vggp_ctx* c, hipStream_t st);
+int vg_comm_wait(vggp_ctx* c, hipStream_t st, const volatile double* seq = nullptr, double want = 0.0);
 // blocked dense Cholesky + inverse for matrices beyond one workgroup (masked.hip); S is destroyed; status != 0 on failure
 #define VG_DENSE_MB 128
 struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };

@@ -328,3 +328,81 @@ hipError_t vg_thin_tail_launch(const VgThinTail* tt, hipStream_t st) {
     hipLaunchKernelGGL(vg_thin_tail_kernel, dim3(1), dim3(1024), vg_thin_tail_lds(tt->r1, tt->r2), st, *tt);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------
+// Cold range finder of the thin chain (api.hip, vg_cold_thin_prepass): r steps of diagonally PIVOTED Cholesky of the Gram matrix
+// G (m x m, numerical rank < r): G ~ sum_i l_i l_i^T, pivot = largest residual diagonal.  The columns l_i span range(G) and are
+// GRADED -- l_i has zeros at the earlier pivots and norm^2 <= the i-th largest residual -- which is what the row-by-row
+// orthonormalisation that follows needs to keep the small range directions apart from the large ones (a random sketch Omega G
+// does not have it: every one of its rows is dominated by lam_1, and so is V1 G for an ungraded basis V1).  The residual update
+// G - sum l l^T itself cancels, so directions below ~1e-8 lam_1 come out with few digits: the thin chain's own pass "Z = V G"
+// (G annihilates what is not range) repairs that, and its miss check decides.  One workgroup of 256 threads per matrix, thread = row;
+// a step is one argmax (wave butterflies + one LDS exchange) and one column update with L in LDS: ~1 us.  Steps whose pivot is not
+// positive (the residual is rounding noise: rank < r) take the fixed pseudo-random row instead.  Output: the r columns as the ROWS
+// of V (r x m).
+#define VP_MAXM 256
+__global__ __launch_bounds__(256) void vg_pivchol_kernel(const VgPivCholArgs a) {
+    const VgPivCholJob j = a.job[blockIdx.x];
+    extern __shared__ double vp_dyn[];
+    double* L = vp_dyn;                                   // [m][r + 1]
+    __shared__ double wmax[4];
+    __shared__ int warg[4];
+    const int tid = threadIdx.x, m = j.m, r = j.r, ld = r + 1;
+    const bool own = tid < m;
+    double d = own ? j.G[(long)tid * m + tid] : -1.0;     // residual diagonal of this thread's row
+    const double d0_floor = 0.0;
+    for (int i = 0; i < r; ++i) {
+        // argmax of the residual diagonal
+        double v = own ? d : -1.0;
+        int arg = tid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off);
+            const int oa = __shfl_xor(arg, off);
+            if (ov > v || (ov == v && oa < arg)) { v = ov; arg = oa; }
+        }
+        if ((tid & 63) == 0) { wmax[tid >> 6] = v; warg[tid >> 6] = arg; }
+        __syncthreads();
+        double best = wmax[0];
+        int p = warg[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (wmax[w] > best || (wmax[w] == best && warg[w] < p)) { best = wmax[w]; p = warg[w]; }
+        double li = 0.0;
+        if (best > d0_floor) {
+            if (own) {
+                double cval = j.G[(long)p * m + tid];     // column p = row p (symmetric): coalesced
+                for (int q = 0; q < i; ++q) cval -= L[tid * ld + q] * L[p * ld + q];
+                li = cval / sqrt(best);
+                if (tid == p) li = sqrt(best);
+            }
+        } else if (own) {
+            li = j.Omega[(long)i * m + tid] * 1e-30;      // (rank < r: an arbitrary direction, scaled out of the way of the residuals)
+        }
+        __syncthreads();                                  // every thread has read row p of L before anyone writes column i
+        if (own) {
+            L[tid * ld + i] = li;
+            d -= li * li;
+            if (tid == p) d = -1.0;                       // a pivot is used once
+            j.V[(long)i * m + tid] = (best > d0_floor) ? li : j.Omega[(long)i * m + tid];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t vg_pivchol_launch(const VgPivCholJob* jobs, int njobs, hipStream_t st) {
+    if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
+    VgPivCholArgs a;
+    size_t lds = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (jobs[i].m < 1 || jobs[i].m > VP_MAXM || jobs[i].r < 1 || jobs[i].r > jobs[i].m || jobs[i].r > 64) return hipErrorInvalidValue;
+        a.job[i] = jobs[i];
+        lds = std::max(lds, (size_t)jobs[i].m * (jobs[i].r + 1) * sizeof(double));
+    }
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vg_pivchol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(VP_MAXM * 65 * sizeof(double)));
+        attr = true;
+    }
+    hipLaunchKernelGGL(vg_pivchol_kernel, dim3(njobs), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
