@@ -157,9 +157,10 @@ def test_trsm_in_place_and_wide(engine):
     assert rel(Rt.cpu().numpy(), sla.solve_triangular(L, R, lower=True)) < 1e-11
 
 
-@pytest.mark.parametrize("n1,n2", [(96, 130), (1024, 1024)])
+@pytest.mark.parametrize("n1,n2", [(96, 130), (1024, 1024), (300, 520), (1000, 648)])
 def test_kron_solve(engine, n1, n2):
-    """BASELINE metric (ii) from the CHOLESKY FACTORS: X = K1^{-1} Y K2^{-T} by four triangular solves, against the CPU oracle
+    """BASELINE metric (ii) from the CHOLESKY FACTORS: X = K1^{-1} Y K2^{-T} (substitution for factors within one 128-block, explicit
+    block-doubling inverses and K_d^-1 = Linv^T Linv products beyond; partial blocks included), against the CPU oracle
     (scipy.linalg.solve_triangular, oracle/kron.py kron_solve) and the size-independent residual K1 X K2^T == Y."""
     K1, _ = Kr.points_factor("matern32", np.linspace(0, 1, n1), np.linspace(0, 1, n1), 0.1 if n1 < 500 else 0.05)
     K2, _ = Kr.points_factor("matern12", np.linspace(0, 1, n2), np.linspace(0, 1, n2), 0.3 if n2 < 500 else 0.2)

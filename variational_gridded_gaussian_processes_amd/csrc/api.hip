@@ -2285,7 +2285,8 @@ extern "C" int vggp_trsm(vggp_ctx* c, const double* L, int64_t m, const double* 
 // Explicit inverse of a lower-triangular factor (n > 128) without ever inverting more than a 16 x 16 block directly:
 // the 128 x 128 diagonal blocks by substitution on the identity (strip kernel, one launch for all blocks of all factors),
 // then block doubling  inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]  with two MFMA GEMM launches per level
-// (128 -> 256 -> 512 -> ...; every pair of every factor in the same launch).  Xinv must be zero above the diagonal blocks.
+// (128 -> 256 -> 512 -> ...; every pair of every factor in the same launch).  The 128-blocks of Xinv above the diagonal are
+// neither written nor read (triangular-aware products): consumers must skip them as well.
 struct VgTriInvSpec { const double* L; long n; const double* Dinv16; double* Xinv; double* tmp; };
 static int tri_inverse_batch(const VgTriInvSpec* sp, int nf, hipStream_t st) {
     VgTrsmJob tj[16];
@@ -2311,12 +2312,16 @@ static int tri_inverse_batch(const VgTriInvSpec* sp, int nf, hipStream_t st) {
                 for (long a0 = 0; a0 + b < n; a0 += 2 * b) {
                     const long c0 = a0 + b, cb = std::min<long>(b, n - c0);           // A = [a0, a0+b), C = [c0, c0+cb)
                     if (g.nprob == VG_GEMM_MAXP) { VG_HIP(vg_gemm_launch(&g, st)); vg_gemm_init(&g); }
-                    if (pass == 0)        // T = B A^-1        (cb x b)
-                        vg_gemm_add(&g, sp[f].L + c0 * n + a0, n, 1, sp[f].Xinv + a0 * n + a0, n, 1, sp[f].tmp + c0 * n + a0, (int)n, (int)cb,
-                                    (int)b, (int)b);
-                    else                  // W = -C^-1 T
-                        vg_gemm_add(&g, sp[f].Xinv + c0 * n + c0, n, 1, sp[f].tmp + c0 * n + a0, n, 1, sp[f].Xinv + c0 * n + a0, (int)n,
-                                    (int)cb, (int)b, (int)cb, 1, 0, 1, 0, -1.0, 0);
+                    int ip;
+                    if (pass == 0) {      // T = B A^-1        (cb x b; A^-1 lower triangular: its upper 128-blocks are never read)
+                        ip = vg_gemm_add(&g, sp[f].L + c0 * n + a0, n, 1, sp[f].Xinv + a0 * n + a0, n, 1, sp[f].tmp + c0 * n + a0, (int)n, (int)cb,
+                                         (int)b, (int)b);
+                        g.p[ip].tri = VG_TRI_B_LOWER;
+                    } else {              // W = -C^-1 T
+                        ip = vg_gemm_add(&g, sp[f].Xinv + c0 * n + c0, n, 1, sp[f].tmp + c0 * n + a0, n, 1, sp[f].Xinv + c0 * n + a0, (int)n,
+                                         (int)cb, (int)b, (int)cb, 1, 0, 1, 0, -1.0, 0);
+                        g.p[ip].tri = VG_TRI_A_LOWER;
+                    }
                 }
             }
             if (g.nprob) VG_HIP(vg_gemm_launch(&g, st));
@@ -2361,17 +2366,37 @@ extern "C" int vggp_kron_solve(vggp_ctx* c, const double* L1, int64_t n1, const 
     double* tmp2 = tmp1 + n1 * n1;
     double* T1 = tmp2 + n2 * n2;                 // two split-K slabs each
     double* T2 = T1 + 2 * n1 * n2;
-    VG_HIP(hipMemsetAsync(Li1, 0, sizeof(double) * (n1 * n1 + n2 * n2), st));
+    // (no clearing of Li: the substitution writes whole diagonal 128-blocks, and every product below skips the 128-blocks above them)
     VgTriInvSpec sp[2] = {{L1, (long)n1, D1, Li1, tmp1}, {L2, (long)n2, D2, Li2, tmp2}};
     if ((rc = tri_inverse_batch(sp, 2, st))) return rc;            // both factors ride in the same launches
-    // Four triangular-aware GEMMs.  A 1024^3 product is 256 tiles = one workgroup per CU, and the triangular skip leaves the
-    // longest tile (full K) on the critical path: it saves energy and L2 traffic, not time.  Splitting the reduction in two
+    // X = P1 Y P2 with P_d = K_d^-1 = Linv_d^T Linv_d: one launch forms both P_d (X^T X of a lower-triangular X: tiles skip the
+    // k-range where either operand vanishes), then TWO dense products instead of four triangular-aware ones -- a 1024^3 product is
+    // 256 tiles = one workgroup per CU, and the triangular skip leaves the longest tile (full K) on the critical path, so each of
+    // the four cost what a dense product costs (40 us at n = 1024).  The error is that of the explicit inverses either way
+    // (eps cond(K_d) per side).  VGGP_KRON_FOUR=1 keeps the four-product form reachable (A/B).
+    static const bool four = getenv("VGGP_KRON_FOUR") != nullptr;
+    VgGemmBatch g;
+    if (!four) {
+        double* P1 = tmp1;                       // (the block-doubling scratch is free again)
+        double* P2 = tmp2;
+        vg_gemm_init(&g);
+        { const int i = vg_gemm_add(&g, Li1, 1, n1, Li1, n1, 1, P1, (int)n1, (int)n1, (int)n1, (int)n1); g.p[i].tri = VG_TRI_A_UPPER_B_LOWER; }
+        { const int i = vg_gemm_add(&g, Li2, 1, n2, Li2, n2, 1, P2, (int)n2, (int)n2, (int)n2, (int)n2); g.p[i].tri = VG_TRI_A_UPPER_B_LOWER; g.p[i].rev = 1; }
+        VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
+        vg_gemm_init(&g);
+        vg_gemm_add(&g, P1, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1);           // P1 Y
+        VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
+        vg_gemm_init(&g);
+        vg_gemm_add(&g, T1, n2, 1, P2, n2, 1, X, (int)n2, (int)n1, (int)n2, (int)n2);           // . P2   (symmetric)
+        VG_HIP(vg_gemm_launch(&g, st, VG_GEMM_TAG_WIDE));
+        return VGGP_OK;
+    }
+    // Four triangular-aware GEMMs.  Splitting the reduction in two
     // (slabs summed on load by the next product, two workgroups per CU) was measured SLOWER (397 vs 336 us for the whole
     // solve: the slab-summing operand path); VGGP_KRON_KSPLIT=2 keeps it reachable.
     const long slab = (long)n1 * n2;
     static const char* kse = getenv("VGGP_KRON_KSPLIT");
     const int ks = kse ? atoi(kse) : 1;
-    VgGemmBatch g;
     vg_gemm_init(&g);
     { const int i = vg_gemm_add(&g, Li1, n1, 1, Y, n2, 1, T1, (int)n2, (int)n1, (int)n2, (int)n1, ks, slab); g.p[i].tri = VG_TRI_A_LOWER; }  // L1inv Y
     const int s1 = g.p[0].ksplit;

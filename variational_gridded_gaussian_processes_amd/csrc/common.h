@@ -72,6 +72,7 @@ struct VgGemmP {
     double* dot_out;
     int dotw_ld;
     int deep;          // set by vg_gemm_launch: this problem runs on the deep-stage tile (gemm.hip vg_gemm_deep_body)
+    int rev;           // 1: tiles in reverse order (deep tile only): a triangular problem's long tiles meet its batch partner's short ones on a CU
 };
 #define VG_TRI_NONE 0
 #define VG_TRI_A_LOWER 1   // op(A)[i][k] = 0 for k > i:  k < roundup128(row0 + T)

@@ -144,6 +144,7 @@ __device__ __forceinline__ void vg_gemm_deep_body(const VgGemmP& p, double* lds,
     } else {
         ks = t / tiles;
         t -= ks * tiles;
+        if (p.rev) t = tiles - 1 - t;
         tm = t / p.tiles_n;
         tn = t - tm * p.tiles_n;
     }
@@ -293,6 +294,7 @@ int vg_gemm_add(VgGemmBatch* b, const double* A, long sa_m, long sa_k, const dou
     p.a_nslab = 1;
     p.a_slab = 0;
     p.tri = VG_TRI_NONE;
+    p.rev = 0;
     p.xcd_group = 0;
     p.dotw = nullptr; p.dot_out = nullptr; p.dotw_ld = 0; p.deep = 0;
     p.tiles_m = (M + VG_BM - 1) / VG_BM;
