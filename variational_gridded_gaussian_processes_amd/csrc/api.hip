@@ -380,6 +380,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     VG_HIP(hipDeviceSynchronize());
     c->desc.x1 = c->desc.x2 = c->desc.grid1 = c->desc.grid2 = nullptr;   // host pointers not retained
     c->have_partials = c->have_step = c->have_masked = false;
+    vg_masked_new_plan(c);
     c->planned = true;
     return VGGP_OK;
 }

@@ -142,6 +142,7 @@ int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st);
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false, bool fused = false,
                         bool apply_ns = false, bool early = false);
 void vg_masked_free(vggp_ctx* c);
+void vg_masked_new_plan(vggp_ctx* c);
 // batch of triangular solves, each in place on its X (api.hip trsm_batch: element (row k, column c) at X[k * sk + c * sc])
 #define VG_TRSM_BLK 128
 struct VgTrsmSpec {

@@ -200,6 +200,9 @@ struct VgMasked {
     bool iter = false;             // iterative step (vggp_elbo_step_masked_iter): none of the M x M / pair-product buffers exist
     void* imem = nullptr;          // its own workspace (VgIter, below)
     size_t ibytes = 0;
+    // the iterative step's kept preconditioner basis: valid, steps since the cold solve, PCG iterations right after it / last step
+    bool ib_valid = false, ib_fresh = false;
+    int ib_age = 0, ib_ref_its = 0, ib_last_its = 0, ib_nbc = 0, ib_maxit = 0;
     double *Sg, *Lg, *Xg, *Sinv, *R, *Phip, *DI, *Tmp;          // M x M (Phip: two of them; Tmp: 128 x M)
     double *PP1, *PP1v, *PP2, *PP2v, *T, *Tv;
     double *UB, *UV, *Zb, *Zv1, *Zv2, *B1s, *B2s;
@@ -255,6 +258,7 @@ static int vgm_prepare(vggp_ctx* c, bool iter = false) {
         return VGGP_OK;
     if (w->mem) { VG_HIP(hipFree(w->mem)); w->mem = nullptr; }
     if (w->imem) { VG_HIP(hipFree(w->imem)); w->imem = nullptr; w->ibytes = 0; }
+    w->ib_valid = false;
     w->M = m1 * m2; w->m1 = (int)m1; w->m2 = (int)m2; w->n1 = c->desc.n1; w->n2 = c->desc.n2; w->scattered = sc; w->iter = iter;
     w->nblk = (int)((w->M + VG_MB - 1) / VG_MB);
     size_t off = 0;
@@ -277,6 +281,11 @@ static int vgm_prepare(vggp_ctx* c, bool iter = false) {
     off = 0;
     vgm_layout(*w, reinterpret_cast<char*>(w->mem), off);
     return VGGP_OK;
+}
+
+void vg_masked_new_plan(vggp_ctx* c) {          // vggp_plan: the iterative step's kept preconditioner basis belongs to the old plan
+    VgMasked* w = reinterpret_cast<VgMasked*>(c->masked);
+    if (w) w->ib_valid = false;
 }
 
 void vg_masked_free(vggp_ctx* c) {
@@ -1012,6 +1021,7 @@ struct VgIter {
     double *col;                                  // per-column scalars: [0] rz, [1] pAp, [2] r0^2, [3] rr, [4] alpha, [5] beta, [6] active, [7] k
     double *Rr1, *Rr2, *Rv1, *Rv2, *RR1, *RRV1, *RR2, *RRV2, *TW, *TWv, *Ex;   // rotated factors and the exact traces' temporaries
     double *dg1, *dg2, *Tq;                       // diag(Q^T Mk Q), m x m temporary
+    double *Qk1, *Qk2;                            // the preconditioner's eigenbasis of the last cold solve (rows = eigenvectors), kept across steps
     double *ts;                                   // [32] scalars
     int* nact;                                    // device word: number of active columns
     int* h_nact;                                  // pinned
@@ -1273,10 +1283,13 @@ static int vgi_prepare(vggp_ctx* c, VgMasked& w, VgIter& it, int nbc, int maxit)
         it.Rr2 = take(m2 * n2); it.Rv2 = take(m2 * n2); it.RR2 = take(m2 * n2); it.RRV2 = take(m2 * n2);
         it.TW = take(n1 * m2); it.TWv = take(n1 * m2); it.Ex = take(M);
         it.dg1 = take(m1); it.dg2 = take(m2); it.Tq = take(mx * mx);
+        it.Qk1 = take(m1 * m1); it.Qk2 = take(m2 * m2);
         it.ts = take(64);
         it.nact = reinterpret_cast<int*>(take(8));
         if (pass == 0) {
             const size_t need = off + 4096;
+            if (w.ibytes < need || w.ib_nbc != nbc || w.ib_maxit != maxit) w.ib_valid = false;      // (the layout moves: the kept basis is gone)
+            w.ib_nbc = nbc; w.ib_maxit = maxit;
             if (w.ibytes < need) {
                 if (w.imem) { VG_HIP(hipFree(w.imem)); w.imem = nullptr; w.ibytes = 0; }
                 VG_HIP(hipMalloc(&w.imem, need));
@@ -1324,9 +1337,19 @@ static int vgi_rot(vggp_ctx* c, const VgMasked& w, const VgIter& it, const doubl
     return gemm1(d1.Qt, 1, m1, it.Tm, (long)nbc * m2, 1, out, nbc * m2, m1, nbc * m2, m1, st);                     // Q1 (.)
 }
 
+#define VGI_ESTALE (-1001)      // internal: the kept preconditioner basis is too far off (the caller repeats the step with a cold solve)
+static int masked_iter_once(vggp_ctx* c, const double* Ym, const double* W, double n_obs, double yy_obs, const double theta[5],
+                            int n_probes, double tol, int max_iter, double* elbo_out, double grad_out[5], vggp_info* info, void* stream);
 extern "C" int vggp_elbo_step_masked_iter(vggp_ctx* c, const double* Ym, const double* W, double n_obs, double yy_obs, const double theta[5],
                                           int n_probes, double tol, int max_iter, double* elbo_out, double grad_out[5], vggp_info* info,
                                           void* stream) {
+    int rc = masked_iter_once(c, Ym, W, n_obs, yy_obs, theta, n_probes, tol, max_iter, elbo_out, grad_out, info, stream);
+    if (rc == VGI_ESTALE) rc = masked_iter_once(c, Ym, W, n_obs, yy_obs, theta, n_probes, tol, max_iter, elbo_out, grad_out, info, stream);
+    if (rc == VGI_ESTALE) { vg_set_error("vggp_elbo_step_masked_iter: internal (stale basis after a cold solve)"); rc = VGGP_ESTATE; }
+    return rc;
+}
+static int masked_iter_once(vggp_ctx* c, const double* Ym, const double* W, double n_obs, double yy_obs, const double theta[5],
+                            int n_probes, double tol, int max_iter, double* elbo_out, double grad_out[5], vggp_info* info, void* stream) {
     if (!c || !c->planned) { vg_set_error("vggp_elbo_step_masked_iter: context not planned"); return VGGP_ESTATE; }
     VG_REQUIRE(Ym && W && theta && elbo_out && grad_out, "vggp_elbo_step_masked_iter: null argument");
     c->have_masked = false;
@@ -1357,18 +1380,47 @@ extern "C" int vggp_elbo_step_masked_iter(vggp_ctx* c, const double* Ym, const d
     double *C0 = w.mpay + 2 * m2 * m2, *C1 = C0 + M, *C2 = C1 + M;
     if ((rc = vgm_colstats(c, w, W, st))) return rc;
     hipLaunchKernelGGL(vgi_transpose_kernel, dim3((unsigned)((n1 + 31) / 32), (unsigned)((n2 + 31) / 32)), dim3(32, 8), 0, st, W, n1, n2, it.Wt);
-    // eigenbasis of the preconditioner: the full-grid path's cold eigensolver on G1, G2
+    bool reused = false;
+    // Eigenbasis of the preconditioner.  Everything below is exact in expectation for ANY orthonormal Q_d and any positive
+    // dP = 1 + rho p l1 l2 -- P~ = (Q1 (x) Q2) diag(dP) (Q1 (x) Q2)^T is then simply another SPD preconditioner with a known
+    // determinant: log|Sigma~| = sum log dP + tr log(P~^-1/2 Sigma~ P~^-1/2), the exact traces are traces against P~^-1 -- so the
+    // cold Jacobi solve of G1, G2 (1.7 ms at m_d = 128, 74 ms at m_d = 256 where the solver works in global memory: 70 % of that
+    // step) runs only on the first step of a plan, every 64 steps, and when the PCG needed 4 iterations more than right after the
+    // last solve; in between the kept basis is reused with the Rayleigh quotients l_i = q_i^T G q_i of the CURRENT Gram matrices.
+    // VGGP_ITER_COLD_BASIS=1: solve every step.
     {
-        VgEigJob ej[2];
+        static const bool always = getenv("VGGP_ITER_COLD_BASIS") != nullptr;
         const double* G[2] = {d1.GH, w.mpay};
-        for (int k = 0; k < 2; ++k) {
-            VgDim& d = c->d[k];
-            ej[k] = VgEigJob{G[k], d.lam0, d.Qt, nullptr, d.gwork, d.rotlog, d.roundlog, d.counters, d.m, d.max_rounds,
-                             (long)vg_eigh_log_bytes(d.m), 0};
-            ej[k].perm = d.perm;
-            ej[k].err = d.status + 1;
+        // (not for RBF factors: rho lam1 lam2 spans eight decades there, and a basis that is 1e-2 off leaves P~^-1 Sigma~ with a
+        //  condition number of 1e4 -- the PCG stalls; measured.  Matern spectra are flat enough: 8 -> 11 -> 13 iterations over 4 % drift)
+        const bool reuse = !always && w.ib_valid && w.ib_age < 64 && w.ib_last_its <= w.ib_ref_its + 4 && d1.kind != VGGP_KIND_RBF &&
+                           d2.kind != VGGP_KIND_RBF;
+        reused = reuse;
+        if (reuse) {
+            double* Qk[2] = {it.Qk1, it.Qk2};
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                VG_HIP(hipMemcpyAsync(d.Qt, Qk[k], sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
+                if ((rc = gemm1(d.Qt, d.m, 1, G[k], d.m, 1, it.Tq, d.m, d.m, d.m, d.m, st))) return rc;         // Q^T-rows times G
+                VGM_LAUNCH1D(vgi_rowdot_kernel, d.m, st, it.Tq, d.Qt, d.m, d.lam0);
+            }
+            ++w.ib_age;
+            w.ib_fresh = false;
+        } else {
+            VgEigJob ej[2];
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                ej[k] = VgEigJob{G[k], d.lam0, d.Qt, nullptr, d.gwork, d.rotlog, d.roundlog, d.counters, d.m, d.max_rounds,
+                                 (long)vg_eigh_log_bytes(d.m), 0};
+                ej[k].perm = d.perm;
+                ej[k].err = d.status + 1;
+            }
+            VG_HIP(vg_eigh_launch(ej, 2, st));
+            VG_HIP(hipMemcpyAsync(it.Qk1, d1.Qt, sizeof(double) * m1 * m1, hipMemcpyDeviceToDevice, st));
+            VG_HIP(hipMemcpyAsync(it.Qk2, d2.Qt, sizeof(double) * m2 * m2, hipMemcpyDeviceToDevice, st));
+            w.ib_valid = false;            // ... until this step has returned without an error
+            w.ib_fresh = true;
         }
-        VG_HIP(vg_eigh_launch(ej, 2, st));
     }
     const double p = n_obs / ((double)n1 * (double)n2);
     const long nb = M * nbc;
@@ -1403,6 +1455,10 @@ extern "C" int vggp_elbo_step_masked_iter(vggp_ctx* c, const double* Ym, const d
         VG_HIP(hipStreamSynchronize(st));
         nact = c->h_out->counters[0][0];
         iters = k + 1;
+        if (reused && nact > 0 && iters > w.ib_ref_its + 12) {      // the kept basis has drifted too far: not worth iterating on
+            w.ib_valid = false;
+            return VGI_ESTALE;
+        }
     }
     if (nact > 0) { vg_set_error("vggp_elbo_step_masked_iter: PCG did not reach %.1e in %d iterations (%d columns left)", tol, max_iter, nact); return VGGP_ENOCONV; }
     // log det: log|P| + the quadratures
@@ -1522,6 +1578,8 @@ extern "C" int vggp_elbo_step_masked_iter(vggp_ctx* c, const double* Ym, const d
     if (status == VGGP_ENOTPD) { vg_set_error("iterative masked step: a factor is not positive definite"); return VGGP_ENOTPD; }
     if (status) { vg_set_error("iterative masked step: the preconditioner's eigensolver failed (status %d)", status); return VGGP_ENOCONV; }
     if (c->h_out->counters[1][3]) { vg_set_error("iterative masked step: the Lanczos quadrature failed (code %d)", c->h_out->counters[1][3]); return VGGP_ENOCONV; }
+    if (w.ib_fresh) { w.ib_valid = true; w.ib_age = 0; w.ib_ref_its = iters; }
+    w.ib_last_its = iters;
     c->have_step = false; c->have_partials = false;
     return VGGP_OK;
 }
