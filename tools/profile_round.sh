@@ -25,6 +25,8 @@ run step_m32 -- $B --kind matern32                                  &&
 VGGP_NO_GRAPH=1 run pmc_fetch --pmc FETCH_SIZE -- $B                &&
 VGGP_NO_GRAPH=1 run pmc_write --pmc WRITE_SIZE -- $B                &&
 run pmc_calib --pmc FETCH_SIZE -- $R/tools/pmc_calib.py             &&
+VGGP_NO_GRAPH=1 run pmc_fetch_slab --pmc FETCH_SIZE -- $B --n1 4096 --n2-local 1024 &&
+VGGP_NO_GRAPH=1 run pmc_write_slab --pmc WRITE_SIZE -- $B --n1 4096 --n2-local 1024 &&
 run factor -- $R/tools/time_factor.py                               &&
 run factor_fetch --pmc FETCH_SIZE -- $R/tools/time_factor.py        &&
 run factor_write --pmc WRITE_SIZE -- $R/tools/time_factor.py        &&
@@ -36,4 +38,5 @@ cd $R
 python3 tools/trace_step.py $O/step_kernel_trace.csv > $O/step_timeline.txt 2>&1
 python3 tools/trace_step.py $O/step_m32_kernel_trace.csv > $O/step_m32_timeline.txt 2>&1
 CALIB_BYTES=134217728 python3 tools/pmc_traffic.py $O/pmc_fetch_counter_collection.csv $O/pmc_write_counter_collection.csv $O/pmc_calib_counter_collection.csv $O/pmc_traffic.json 1024 1024 128 > $O/pmc_traffic.log 2>&1
+CALIB_BYTES=134217728 python3 tools/pmc_traffic.py $O/pmc_fetch_slab_counter_collection.csv $O/pmc_write_slab_counter_collection.csv $O/pmc_calib_counter_collection.csv $O/pmc_traffic_slab_1024x4096.json 4096 1024 128 > $O/pmc_traffic_slab.log 2>&1
 ls $O | head -50

@@ -584,7 +584,9 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
             vg_set_error("internal: the early projection was requested where it cannot run");
             return VGGP_ESTATE;
         }
-        vg_gemm_add(&gsp, d2.AD, n2, 1, Y, n1, 1, c->Sp, (int)n1, (int)(2 * m2), (int)n1, (int)n2, VG_SP_SLABS, 2L * m2 * n1);
+        // split-K only as far as the chip needs it: the plan's split of S (256 workgroups) capped at VG_SP_SLABS -- 4 slabs at 1024^2, ONE
+        // for a 1024 x 4096 slab, whose 64 x 64 tiles fill the chip by themselves (no slab traffic, two substitution jobs instead of eight)
+        vg_gemm_add(&gsp, d2.AD, n2, 1, Y, n1, 1, c->Sp, (int)n1, (int)(2 * m2), (int)n1, (int)n2, std::min(c->st_split, VG_SP_SLABS), 2L * m2 * n1);
         sp_slabs = gsp.p[0].ksplit;
         if (c->prof) {                 // profiling mode: every launch group by itself -- the pass over Y as a launch of its own
             vg_gemm_xcd_group(&gsp, 0);
