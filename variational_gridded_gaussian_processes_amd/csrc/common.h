@@ -1,5 +1,8 @@
 // Shared declarations for the libvggp_hip.so translation units (gfx950 only).
 #pragma once
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libvggp_hip is written for gfx950 (MI355X) only: kernels rely on its wave64 barrier semantics, MFMA shapes and LDS size"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vggp.h"

@@ -257,10 +257,30 @@ class KroneckerStructure(torch.nn.Module):
                 self._engine.set_inducing(1, g2)
             self._plan_key = key
         elif not self._planned or self._plan_token != self._engine.plan_token or key != self._plan_key:
+            if self._scattered or self._masked:
+                self._check_dense_workspace(basis, g1, g2)
             self._engine.plan(self.kind, basis, g1, self._x1, self.kind, basis, g2, self._x2, warm_start=self._warm,
                               b0_f32_kdelta=self._f32_mesh(), scattered=self._scattered)
             self._planned = True
             self._plan_token, self._plan_key = self._engine.plan_token, key
+
+    def _check_dense_workspace(self, basis, g1, g2):
+        """The masked / scattered steps work on dense M x M matrices (M = m1 m2 <= 16384; ~10 M^2 doubles) and, for scattered points,
+        on four m_d^2 x N pair-product buffers that are not chunked over N: say so here, with the numbers, instead of failing in
+        hipMalloc at the first step."""
+        m1 = len(g1) - 1 if basis == "b0" else (2 * (len(g1) - 3) + 1 if basis == "vff" else len(g1))
+        m2 = len(g2) - 1 if basis == "b0" else (2 * (len(g2) - 3) + 1 if basis == "vff" else len(g2))
+        M, N = m1 * m2, int(self._nobs)
+        if M > 16384:
+            raise ValueError(f"{type(self).__name__}: X is {'scattered' if self._scattered else 'a grid with holes'}, which takes the dense "
+                             f"M-space solver, and M = m1 * m2 = {m1} * {m2} = {M} exceeds its limit of 16384 "
+                             f"(Engine.elbo_step_masked_iter handles larger M on masked grids)")
+        n_pair = N if self._scattered else max(len(self._x1), len(self._x2))
+        need = 8.0 * (10.0 * M * M + 2.0 * (m1 * m1 + m2 * m2) * n_pair)
+        free = torch.cuda.mem_get_info(self._engine.device)[0] if torch.cuda.is_available() else None
+        if free is not None and need > free:
+            raise ValueError(f"{type(self).__name__}: the dense M-space workspace needs about {need / 2**30:.1f} GiB (M = {M}, N = {N}, "
+                             f"m_d = {m1}, {m2}: ~10 M^2 + 2 (m1^2 + m2^2) N doubles) but {free / 2**30:.1f} GiB of device memory are free")
 
     def _theta(self) -> torch.Tensor:
         return torch.stack([self.kernel_1.base_kernel.lengthscale.reshape(()),
