@@ -412,44 +412,60 @@ __device__ void vg_chol_mfma(const VgCholJob& J, int lvl, double* Lm, double* Di
 #pragma unroll
             for (int c = 0; c < 4; ++c) { a[c] = Db[i * 17 + 4 * q + c]; x[c] = (i == 4 * q + c) ? 1.0 : 0.0; }
             bool good = true;
-            // TWO pivot columns per LDS round trip: columns k and k+1 (and rows k, k+1 of the running inverse) are published
-            // together; every lane then forms both multipliers itself -- the second pivot is the 2 x 2 Schur complement
-            // p2 = a(k+1,k+1) - a(k+1,k)^2 / p1 -- and applies the rank-2 update.  Halves the round trips of the chain.
+            // FOUR pivot columns per LDS round trip: columns k .. k+3 (and rows k .. k+3 of the running inverse) are published
+            // together; every lane then runs the four eliminations of the 4 x 4 pivot block itself, on the handful of entries of
+            // those columns it needs -- its own row, the pivot rows, the rows that mirror its own columns (the trailing matrix
+            // stays symmetric, so row k+r at column j is column k+r at row j) -- and applies one rank-4 update.  The chain is
+            // 4 round trips per diagonal block instead of 8 (two pivots each: 910 cycles per pair, 24 of the launch's 42 us).
 #pragma unroll
-            for (int k = 0; k < VG_CB; k += 2) {
-                if (q == (k >> 2)) { colbuf[k * 16 + i] = a[k & 3]; colbuf[(k + 1) * 16 + i] = a[(k + 1) & 3]; }
-                if (i == k) {
+            for (int k = 0; k < VG_CB; k += 4) {
+                if (q == (k >> 2)) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xrow[4 * q + c] = x[c];
+                    for (int c = 0; c < 4; ++c) colbuf[(k + c) * 16 + i] = a[c];
                 }
-                if (i == k + 1) {
+                if ((i >> 2) == (k >> 2)) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xrow[16 + 4 * q + c] = x[c];
+                    for (int c = 0; c < 4; ++c) xrow[(i & 3) * 16 + 4 * q + c] = x[c];
                 }
                 VG_WAVE_SYNC();
-                const double p1 = colbuf[k * 16 + k], m21 = colbuf[k * 16 + k + 1], d2 = colbuf[(k + 1) * 16 + k + 1];
-                const double li1 = colbuf[k * 16 + i], li2 = colbuf[(k + 1) * 16 + i];
-                double lj1[4], lj2[4], xa[4], xb[4];
+                double Cp[4][4], Ci[4], Cj[4][4], Yr[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    lj1[c] = colbuf[k * 16 + 4 * q + c]; lj2[c] = colbuf[(k + 1) * 16 + 4 * q + c];
-                    xa[c] = xrow[4 * q + c]; xb[c] = xrow[16 + 4 * q + c];
+                for (int r = 0; r < 4; ++r) {
+                    Ci[r] = colbuf[(k + r) * 16 + i];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        Cp[r][c] = colbuf[(k + r) * 16 + k + c];
+                        Cj[r][c] = colbuf[(k + r) * 16 + 4 * q + c];
+                        Yr[r][c] = xrow[r * 16 + 4 * q + c];
+                    }
                 }
-                if (!(p1 > 0.0) || !(p1 < 1.0e300)) { good = false; break; }       // wave-uniform
-                const double g = m21 * vg_crcp(p1);
-                const double p2 = d2 - g * m21;
-                if (!(p2 > 0.0) || !(p2 < 1.0e300)) { good = false; break; }
-                const double l1 = (i > k) ? li1 * vg_crcp(p1) : 0.0;
-                const double c2 = li2 - l1 * m21;                                  // column k+1 after step k (unscaled)
-                const double l2 = (i > k + 1) ? c2 * vg_crcp(p2) : 0.0;
-                VG_WAVE_SYNC();                                                    // everybody has read column k+1 ...
-                if (q == 0 && i > k) colbuf[(k + 1) * 16 + i] = c2;               // ... before it is replaced by its final value
+                double l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double pr = Cp[r][r];
+                    if (!(pr > 0.0) || !(pr < 1.0e300)) { good = false; break; }           // wave-uniform
+                    const double inv = vg_crcp(pr);
+                    l[r] = (i > k + r) ? Ci[r] * inv : 0.0;
+#pragma unroll
+                    for (int t = r + 1; t < 4; ++t) {
+                        const double f = Cp[r][t] * inv;                                   // multiplier of pivot row k+t at pivot k+r
+#pragma unroll
+                        for (int sidx = t; sidx < 4; ++sidx) Cp[t][sidx] -= Cp[r][sidx] * f;
+                        Ci[t] -= Ci[r] * f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { Cj[t][c] -= Cj[r][c] * f; Yr[t][c] -= Yr[r][c] * f; }
+                    }
+                }
+                if (!good) break;
+                VG_WAVE_SYNC();                                                    // everybody has read columns k+1 .. k+3 ...
+                if (q == 0 && i > k) {                                             // ... before they are replaced by their final values
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) colbuf[(k + t) * 16 + i] = Ci[t];
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const double r2 = lj2[c] - g * lj1[c];                         // row k+1 after step k
-                    const double y2 = xb[c] - g * xa[c];
-                    a[c] -= l1 * lj1[c] + l2 * r2;
-                    x[c] -= l1 * xa[c] + l2 * y2;
+                    a[c] -= l[0] * Cj[0][c] + l[1] * Cj[1][c] + l[2] * Cj[2][c] + l[3] * Cj[3][c];
+                    x[c] -= l[0] * Yr[0][c] + l[1] * Yr[1][c] + l[2] * Yr[2][c] + l[3] * Yr[3][c];
                 }
             }
             if (good) {
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(512) void vg_chol_mfma_kernel(const VgCholArgs a, c
     }
     __shared__ double Db[16 * 17];
     __shared__ double colbuf[16 * 16];
-    __shared__ double xrow[2 * 16];
+    __shared__ double xrow[4 * 16];
     __shared__ double sdv[16];
     __shared__ int s_i[4];
     const VgCholJob& J = a.job[blockIdx.x >> 2];
