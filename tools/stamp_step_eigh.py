@@ -25,7 +25,7 @@ print("info", info)
 for which, name in ((1, "ritz (r x r)"), (0, "main")):
     for dim in (0, 1):
         buf = (C.c_uint64 * 8)()
-        mm = 24 if which == 1 else m      # the Ritz problem is sub_r x sub_r (24 on this workload)
+        mm = 20 if which == 1 else m      # the Ritz problem is sub_r x sub_r (20 on this workload)
         rc = e.lib.vggp_debug_read_gwork(e._h, dim, which, buf, mm * mm + 8, 64)
         t = np.array(list(buf)).astype(float) * 10.0 / 1e3
         print(f"{name} dim {dim}: rc {rc}  load+norm {t[1]-t[0]:.1f}  dense {t[2]-t[1]:.1f}  sparse {t[3]-t[2]:.1f}  sort+lam+DONE {t[4]-t[3]:.1f} | producer {t[4]-t[0]:.1f}  replay-0 done at {t[5]-t[0]:.1f} us")
