@@ -536,12 +536,11 @@ def timed_loop(eng, Y, yy, kind, x1, x2, m, warm, steps, warmup):
     import torch
     g = np.linspace(0, 1, m)
     eng.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=warm)
-    opt = Adam(raw_start(), lr=0.01)
+    opt = FitLoop5(raw_start(), lr=0.01)          # (the headline's host loop: plain floats, no numpy per-call overhead)
 
     def one():
-        raw = opt.x
-        e, gr, info = eng.elbo_step(Y, yy, theta_from_raw(raw.copy()))
-        opt.step(-(gr / (1.0 + np.exp(-raw))))
+        e, gr, info = eng.elbo_step(Y, yy, opt.theta())
+        opt.update(gr)
 
     for _ in range(warmup):
         one()

@@ -521,8 +521,9 @@ static int vg_chol_big_enqueue(vggp_ctx* c, const int* dims, int ndims, hipStrea
 }
 
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce, bool extrap, bool fused, bool apply_ns,
-                        bool early) {
-    // early (thin chain of a fused single-rank step, finish_enqueue): the pass over Y is taken BEFORE the whitening --
+                        int early) {
+    // early (1: thin chain of a fused single-rank step, finish_enqueue; 2: the regular warm chains, where [C;C1;C2] then is the first
+    // rider of the eigensolver chain instead of S): the pass over Y is taken BEFORE the whitening --
     // S' = [A2;dA2] Y needs nothing but the factor build, so it rides in the Cholesky launch (250 idle CUs for 43 us), and
     // S = L2^-1 S' is a handful of extra strips of the substitution launch (L^-1 (A Y) instead of (L^-1 A) Y: the same
     // substitution, applied to other right-hand sides).  [C;C1;C2] is then complete before the Ritz solve and nothing that touches
@@ -580,7 +581,7 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         //  partials half of a multi-rank step -- reduce: [C;C1;C2] shares the Gram launch and the slab reduction fills the payload)
         const bool ok_fused = fused && !reduce && (vg_ride(c) || c->prof);
         const bool ok_partials = reduce;                 // (also the cold thin step: fused, reduced operands)
-        if (!(dinv_path && !any_big && !ns_on_chol && (ok_fused || ok_partials) && Y && sx == st)) {
+        if (!(dinv_path && !any_big && (ok_fused || ok_partials) && Y && sx == st)) {
             vg_set_error("internal: the early projection was requested where it cannot run");
             return VGGP_ESTATE;
         }
@@ -595,7 +596,17 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         }
     }
     if (!any_big) {
-        VG_HIP(vg_chol_launch(cj, 2, st, (early && !c->prof) ? &gsp : (ns_on_chol ? &gns : nullptr)));
+        // riders of the Cholesky launch: the early pass over Y and / or the Newton-Schulz step of the predicted start basis
+        VgGemmBatch gr2 = gns;
+        if (early && !c->prof) {
+            gr2 = gsp;
+            if (ns_on_chol)
+                for (int k = 0; k < 2; ++k) {
+                    VgDim& d = c->d[k];
+                    vg_gemm_add(&gr2, d.Wp, d.m, 1, d.Ep, d.m, 1, d.Fp, d.m, d.m, d.m, d.m, 1, 0, 1, 0, -0.5, 1);
+                }
+        }
+        VG_HIP(vg_chol_launch(cj, 2, st, ((early && !c->prof) || ns_on_chol) ? &gr2 : nullptr));
     } else {
         // a factor beyond one 128-block: blocked (vg_chol_big_enqueue); a small partner keeps the one-launch MFMA kernel.  Either
         // way the launch leaves L0 and the diagonal-block inverses only; L0^-1 comes out of the substitution below.
@@ -724,7 +735,9 @@ int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream
         add_gram(&g);
         add_ns(&g);
         VG_HIP(vg_gemm_launch(&g, st));
-        c->ride_proj = gp; c->ride_cc = gc; c->ride_pending = !early;      // (early: S exists already, finish_enqueue places [C;C1;C2] itself)
+        c->ride_proj = gp; c->ride_cc = gc;
+        c->ride_pending = early != 1;      // (thin chain: S exists already and finish_enqueue places [C;C1;C2] itself)
+        c->ride_stage0 = early == 2 ? 1 : 0;
     } else {
         if (sp == st) add_gram(&gc);
         VG_HIP(vg_gemm_launch(&gc, sp));
@@ -776,7 +789,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
     const long ccs = 3L * m1 * m2;
     VgGemmBatch g;
     const bool ride = from_slabs && c->ride_pending;      // the projection launches were deferred to this chain (vg_partials_enqueue)
-    int ride_stage = 0;                                   // 0: S pending, 1: [C;C1;C2] pending, 2: done
+    int ride_stage = ride ? c->ride_stage0 : 0;           // 0: S pending, 1: [C;C1;C2] pending (S came out of the early projection), 2: done
 
     // 7. eigendecompositions (optionally warm-started from the previous step's basis)
     hipStream_t sx = vg_side(c, st);
@@ -1128,8 +1141,11 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         if (refine) {
             VgRefineJob rj[2];
             for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, 0.0}; }
-            VG_HIP(vg_refine_launch(rj, 2, st, ride ? &c->ride_proj : nullptr));        // E -> U, I + E -> TH   (+ rider: S = [B2;V2] Y)
-            if (ride) ride_stage = 1;
+            {   // E -> U, I + E -> TH   (+ rider: S = [B2;V2] Y, or [C;C1;C2] when S came out of the early projection)
+                const VgGemmBatch* rr = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
+                VG_HIP(vg_refine_launch(rj, 2, st, rr));
+                if (rr) ++ride_stage;
+            }
             VG_MARK(9);
             vg_gemm_init(&g);
             for (int k = 0; k < 2; ++k) {
@@ -1763,9 +1779,15 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
     }
     const bool thin_early = thin && !no_early && !no_ride && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st &&
                             getenv("VGGP_CHOL_LEGACY") == nullptr;
+    // the regular warm chains (refinement + polish, Newton chain) take the early pass over Y as well: [C;C1;C2] then rides where S
+    // used to (beside the refinement kernel) and the main solve carries nothing.  VGGP_NO_EARLY_REG=1: riders as in round 2.
+    static const bool no_early_reg = getenv("VGGP_NO_EARLY_REG") != nullptr;
+    const bool early_reg = warm && !thin && !subspace && !no_early && !no_early_reg && !no_ride && c->desc.m1 <= 128 && c->desc.m2 <= 128 &&
+                           vg_side(c, st) == st && getenv("VGGP_CHOL_LEGACY") == nullptr && (vg_ride(c) || c->prof);
+    const int early_mode = thin_early ? 1 : (early_reg ? 2 : 0);
     rc = run_graph(c, warm ? (thin ? VG_G_STEP_WARM_T : newton ? VG_G_STEP_WARM_N : subspace ? VG_G_STEP_WARM_S : extrap ? (refine ? VG_G_STEP_WARM_XR : VG_G_STEP_WARM_X) : VG_G_STEP_WARM)
                             : VG_G_STEP_COLD, key, st, [&] {
-        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns, thin_early);
+        const int r1 = vg_partials_enqueue(c, Y, c->payload, st, /*reduce=*/!warm, extrap, /*fused=*/true, apply_ns, early_mode);
         return r1 ? r1 : finish_enqueue(c, c->payload, yy_total, warm, st, false, /*from_slabs=*/warm, extrap, refine, subspace, thin, newton,
                                         thin_early);
     }, extrap && !apply_ns);

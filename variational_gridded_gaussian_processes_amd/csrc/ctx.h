@@ -58,6 +58,7 @@ struct vggp_ctx {
     int st_split = 1, cc_split = 1;
     int st_slabs = 1;                            // ... of S = [B2;V2] Y
     bool dinv_valid = false;                     // Dinv0 holds the diagonal-block inverses of the current L0 (m <= 128 Cholesky path)
+    int ride_stage0 = 0;                         // first pending rider of the fused warm step: 0 = S, 1 = [C;C1;C2] (S came out of the early projection)
     int gh_slabs[2] = {1, 1}, cc_slabs = 1;      // split-K slab counts actually produced by the last partials launch
     long payload_len = 0;
     bool have_partials = false, have_step = false, have_masked = false;
@@ -140,7 +141,7 @@ int vg_comm_wait(vggp_ctx* c, hipStream_t st, const volatile double* seq = nullp
 struct VgDenseChol { double *S, *L, *X, *DI, *Tmp, *scratch, *jit; int* status; long M; double* Sinv; };
 int vg_blocked_chol_inverse(const VgDenseChol& w, hipStream_t st);
 int vg_partials_enqueue(vggp_ctx* c, const double* Y, double* payload, hipStream_t st, bool reduce = true, bool extrap = false, bool fused = false,
-                        bool apply_ns = false, bool early = false);
+                        bool apply_ns = false, int early = 0);      // early: 1 = thin chain, 2 = regular warm chains ([C;C1;C2] is then the first rider)
 void vg_masked_free(vggp_ctx* c);
 void vg_masked_new_plan(vggp_ctx* c);
 // batch of triangular solves, each in place on its X (api.hip trsm_batch: element (row k, column c) at X[k * sk + c * sc])
