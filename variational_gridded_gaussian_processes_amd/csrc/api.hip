@@ -1296,7 +1296,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
 // (variant, data pointers) and replayed; hyper-parameters travel through the pinned theta buffer.
 enum { VG_G_PARTIALS = 0, VG_G_PARTIALS_X, VG_G_FINISH_COLD, VG_G_FINISH_WARM, VG_G_FINISH_WARM_X, VG_G_STEP_COLD, VG_G_STEP_WARM,
        VG_G_STEP_WARM_X, VG_G_FINISH_WARM_XR, VG_G_STEP_WARM_XR, VG_G_FINISH_WARM_S, VG_G_STEP_WARM_S, VG_G_FINISH_WARM_T, VG_G_STEP_WARM_T,
-       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_PARTIALS_E, VG_G_FINISH_WARM_TE, VG_G_STEP_COLD_T, VG_G_COUNT };
+       VG_G_FINISH_WARM_N, VG_G_STEP_WARM_N, VG_G_PARTIALS_E, VG_G_FINISH_WARM_TE, VG_G_STEP_COLD_T, VG_G_PARTIALS_XE, VG_G_COUNT };
 static_assert(VG_G_COUNT <= 20, "vggp_ctx::gexec");
 // _T: thin chain (subspace start without a complement basis, thin.hip); _N: Newton chain
 // _S: subspace start (see finish_enqueue)
@@ -1715,10 +1715,14 @@ static int elbo_step_once(vggp_ctx* c, const double* Y, double yy_total, const d
         // thin chain: the pass over the rank's slab of Y rides beside the Cholesky (vg_partials_enqueue, early), the finish half places
         // the small products of the reduced [C;C1;C2] as the fused single-rank step does
         static const bool no_early_mr = getenv("VGGP_NO_EARLY") != nullptr;
-        const bool thin_early = thin && !no_early_mr && !extrap && !c->prof && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st &&
-                                getenv("VGGP_CHOL_LEGACY") == nullptr;
-        rc = run_graph(c, thin_early ? VG_G_PARTIALS_E : extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, kp, st,
-                       [&] { return vg_partials_enqueue(c, Y, c->payload, st, true, extrap, false, apply_ns, thin_early); }, extrap && !apply_ns);
+        const bool early_ok = !no_early_mr && !c->prof && c->desc.m1 <= 128 && c->desc.m2 <= 128 && vg_side(c, st) == st &&
+                              getenv("VGGP_CHOL_LEGACY") == nullptr;
+        const bool thin_early = thin && early_ok && !extrap;
+        // (the regular warm chains take the early association too, as in the fused single-rank step: the two must agree to rounding)
+        static const bool no_early_reg_mr = getenv("VGGP_NO_EARLY_REG") != nullptr;
+        const bool early_mr = thin_early || (warm && !thin && !subspace && early_ok && !no_early_reg_mr);
+        rc = run_graph(c, early_mr ? (extrap ? VG_G_PARTIALS_XE : VG_G_PARTIALS_E) : extrap ? VG_G_PARTIALS_X : VG_G_PARTIALS, kp, st,
+                       [&] { return vg_partials_enqueue(c, Y, c->payload, st, true, extrap, false, apply_ns, early_mr ? 1 : 0); }, extrap && !apply_ns);
         {
             // fault injection for the failure-path test (tests/test_gpu_dist.py): VGGP_FAULT_PARTIALS_AT=<step number>
             static const long fault_at = [] { const char* e = getenv("VGGP_FAULT_PARTIALS_AT"); return e ? atol(e) : -1L; }();
