@@ -932,6 +932,39 @@ def test_iterative_masked_step_keeps_its_preconditioner_basis(engine, kind, basi
     assert max(its) <= its[0] + 8, its
 
 
+def test_b1_hats_on_a_padded_mesh_take_the_newton_chain(engine):
+    """B1 hats on a mesh padded beyond the data (the reference's Gridded ASVGP, gridded_kronecker_structure.py:699-724): the hats
+    without data span an EXACT null space of the Gram matrix that turns with the lengthscale.  Its block of S G S^T has O(1)
+    first-order quotients inside -- which used to reject every warm start (two dense sweeps per step) -- but only the range-null
+    rotations matter: the Newton chain leaves pairs of previously-null rows alone (VgRefineJob::lam_prev) and converges
+    quadratically.  Trajectory against the oracle; the chain must actually be taken."""
+    n, m, pad = 512, 96, 6
+    X, y, x1, x2 = D.gen_grid(n, n)
+    del X
+    d = 1.0 / (m - 1 - 2 * pad)
+    g = np.linspace(-pad * d, 1 + pad * d, m)
+    f1, f2 = Kr.Factor("b1", "matern12", g, x1), Kr.Factor("b1", "matern12", g, x2)
+    engine.plan("matern12", "b1", g, x1, "matern12", "b1", g, x2, warm_start=True)
+    Y = torch.tensor(y.reshape(n, n), device=DEV)
+    yy = engine.sumsq(Y)
+    base = np.array([0.2, 0.25, 1.0, 0.9, 0.01])
+    newton_steps = 0
+    for k in range(16):
+        theta = base * (1.0 + 0.004 * k)
+        elbo, grad, info = engine.elbo_step(Y, yy, theta)
+        assert info["status"] == 0
+        if k in (0, 6, 11, 15):
+            ref = Kr.elbo_step(y.reshape(n, n), f1, f2, theta)
+            assert abs(elbo - ref.elbo) <= 1e-8 * abs(ref.elbo), (k, elbo, ref.elbo)
+            assert rel(grad, ref.grad) < 1e-6, (k, rel(grad, ref.grad))
+        if k >= 4 and sum(info["rounds"]) == 0:
+            newton_steps += 1
+    assert newton_steps >= 6, newton_steps
+    mean, var = engine.qv()
+    rm, rv = Kr.q_v(Kr.elbo_step(y.reshape(n, n), f1, f2, theta))
+    assert rel(mean.cpu().numpy(), rm) < 1e-6 and rel(var.cpu().numpy(), rv) < 1e-5
+
+
 # ---- Newton chain: warm full-rank Gram matrices without a single-workgroup sweep ------------------------------------------------
 @pytest.mark.parametrize("kind,m,n", [("matern32", 256, 512), ("matern12", 192, 384)])
 def test_newton_chain_tracks_the_oracle(engine, kind, m, n):

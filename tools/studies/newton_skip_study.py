@@ -25,13 +25,14 @@ ell = 0.2
 Gs = [gram(ell * (1 + dl) ** k) for k in range(3)]
 Qa = np.linalg.eigh(Gs[0])[1].T          # rows = eigenvectors
 Qb = np.linalg.eigh(Gs[1])[1].T
-def newton(S, G, tag, emax=0.3, noise=1e-13, skip=True):
+def newton(S, G, tag, emax=0.3, noise=1e-13, skip=True, nullset=None):
     for it in range(iters + 1):
         Gw = S @ G @ S.T
         dg = np.diag(Gw).copy(); off = Gw - np.diag(dg)
         acc = 1e-11 * np.linalg.norm(Gw) / m
         nfl = noise * np.abs(dg).max()
         live = ~((np.abs(dg)[:, None] <= nfl) & (np.abs(dg)[None, :] <= nfl))
+        if nullset is not None: live &= ~(nullset[:, None] & nullset[None, :])
         worst = np.abs(off * live).max()
         i, j = np.unravel_index(np.argmax(np.abs(off * live)), off.shape)
         print(f"  {tag} it {it}: max offdiag / accept = {worst / acc:9.2e}  at ({i},{j}) g_ii {dg[i]:.2e} g_jj {dg[j]:.2e}   orth err {np.abs(S @ S.T - np.eye(m)).max():.1e}")
@@ -49,3 +50,10 @@ def newton(S, G, tag, emax=0.3, noise=1e-13, skip=True):
 U = Qb @ Qa.T
 print("previous basis as the start:"); newton(Qb.copy(), Gs[2], "prev")
 print("extrapolated start U Qb:"); S0 = U @ Qb; newton(S0, Gs[2], "extr")
+
+# static null set: rows whose eigenvalue was numerically zero in the previous step (sorted ascending by eigh: the first ones)
+lamb = np.linalg.eigvalsh(Gs[1])
+nullset = lamb <= 1e-12 * lamb.max()
+print("static null set of", nullset.sum(), "rows:")
+newton(Qb.copy(), Gs[2], "prev+nullset", nullset=nullset)
+newton(U @ Qb, Gs[2], "extr+nullset", nullset=nullset)

@@ -30,6 +30,8 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 #define VG_CHOL_MAXJOBS_HOST 8
 #define VG_SP_SLABS 4             // split-K slabs of the early projection S' = [A2;dA2] Y (riding in the Cholesky launch)
 #define VG_NEWTON_TOL 1e-12      // off-diagonal threshold of the Newton chain's rotations, relative to ||Gw||_F / m
+#define VG_NEWTON_NULL 1e-12     // rows whose eigenvalue was below this fraction of the largest in the PREVIOUS step form the known null space:
+                                 // pairs inside it are neither rotated nor judged (VgRefineJob::lam_prev)
 #define VG_NEWTON_NOISE 1e-13    // diagonal entries below this fraction of the largest are "at the rounding floor" (VgRefineJob::noise)
 #define VG_NEWTON_ACCEPT 1e-11   // ... of its convergence check: Gw = S G S^T comes out of two GEMMs with ~ eps sqrt(m) ||G|| of rounding noise per
                                  // element, 2e-15 ||G|| at m = 256 against 4e-15 ||G||_F for 1e-12 -- the chain converged TO the threshold and
@@ -1034,6 +1036,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; vg_gemm_add(&g, d.TM, d.m, 1, Scur[k], 1, d.m, d.Gw, d.m, d.m, d.m, d.m); }
         VG_HIP(vg_gemm_launch(&g, st));
         VG_MARK(12);
+        static const bool newton_null = getenv("VGGP_NO_NULL_SKIP") == nullptr;
         int bi = 0;                                                           // rotation of the three basis buffers E, X, F
         for (int it = 0; it < newton; ++it) {
             VgRefineJob rj[2];
@@ -1041,6 +1044,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
                 VgDim& d = c->d[k];
                 rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, VG_NEWTON_TOL};
                 rj[k].emax = 0.3; rj[k].flag = d.counters2; rj[k].noise = VG_NEWTON_NOISE;
+                if (newton_null) { rj[k].lam_prev = d.lam0; rj[k].null_cut = VG_NEWTON_NULL; }
             }
             const VgGemmBatch* rd = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
             VG_HIP(vg_refine_launch(rj, 2, st, rd));                           // E -> U, I + E -> TH  (+ riders: S, then [C;C1;C2])
@@ -1089,6 +1093,7 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         for (int k = 0; k < 2; ++k) {
             VgDim& d = c->d[k];
             nj[k] = VgNewtonCheckJob{d.Gw, d.lam0, d.counters, d.status + 1, d.counters2, d.m, newton, VG_NEWTON_ACCEPT, VG_NEWTON_NOISE};
+            if (newton_null) nj[k].null_cut = VG_NEWTON_NULL;
             VG_HIP(hipMemcpyAsync(d.Qt, Scur[k], sizeof(double) * d.m * d.m, hipMemcpyDeviceToDevice, st));
         }
         VG_HIP(vg_newton_check_launch(nj, 2, st));
@@ -1140,7 +1145,12 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
         // gets E = 0 from the kernel and the eigensolver proceeds as usual.
         if (refine) {
             VgRefineJob rj[2];
-            for (int k = 0; k < 2; ++k) { VgDim& d = c->d[k]; rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, 0.0}; }
+            static const bool null_skip = getenv("VGGP_NO_NULL_SKIP") == nullptr;
+            for (int k = 0; k < 2; ++k) {
+                VgDim& d = c->d[k];
+                rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, 0.0};
+                if (null_skip) { rj[k].lam_prev = d.lam0; rj[k].null_cut = 1e-12; }
+            }
             {   // E -> U, I + E -> TH   (+ rider: S = [B2;V2] Y, or [C;C1;C2] when S came out of the early projection)
                 const VgGemmBatch* rr = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
                 VG_HIP(vg_refine_launch(rj, 2, st, rr));
@@ -1576,7 +1586,11 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     {
         const bool polished = ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1);
         c->newton_next = c->cur_newton > 0 ||
-                         (c->last_warm && c->cur_extrap && !c->cur_thin && !polished && (c->h_out->counters[0][0] + c->h_out->counters[1][0]) > 0);
+                         (c->last_warm && c->cur_extrap && !c->cur_thin && !polished && (c->h_out->counters[0][0] + c->h_out->counters[1][0]) > 0) ||
+                         // ... or ended in the polish only after more than a sweep and a half of rotations (B1 hats on a padded mesh: two
+                         // dense sweeps per step, then the polish; an occasional single sweep of a Matern-3/2 step does not count)
+                         (c->last_warm && c->cur_extrap && !c->cur_thin &&
+                          (2 * c->h_out->counters[0][0] >= 3 * c->d[0].m || 2 * c->h_out->counters[1][0] >= 3 * c->d[1].m));
     }
     if (++c->warm_run >= 512) {                                // periodic cold restart: bounds the drift of orthogonality
         c->warm_run = 0;

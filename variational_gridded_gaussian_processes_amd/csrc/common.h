@@ -217,11 +217,18 @@ struct VgRefineJob { const double* Gw; double* E; double* R1; int m; double tol;
                      double noise = 0.0;     // > 0: pairs whose two diagonal entries are both below noise * max diagonal are left alone
                                              // (a cluster at the rounding floor: any orthonormal basis of it serves -- what the ELBO sees of
                                              // it is its trace -- and its quotients g_ij / (g_jj - g_ii) are noise over noise)
+                     const double* lam_prev = nullptr;   // optional: the previous step's eigenvalues in the row order of the start basis; pairs
+                     double null_cut = 0.0;              // of rows that were BOTH below null_cut * largest then are left alone (a null space --
+                                                         // B1 hats without data, the Fourier features' null combinations -- turns with the
+                                                         // hyper-parameters, so its block of Gw is delta^2 lam_range with O(1) quotients inside,
+                                                         // but only the range-null rotations matter: any basis of the null space serves)
 };
 // Newton chain (api.hip finish_enqueue): after the last iteration -- eigenvalues = diag(Gw), convergence check (largest
 // off-diagonal element against tol * ||Gw||_F / m), numerical rank; counters [0] = 0, [1] = iterations | rank << 8, [2] = 0,
 // [3] = 0; bit 1 of *err (-> VG_ESUBMISS: the host repeats the step on the regular chain) when not converged or rejected.
-struct VgNewtonCheckJob { const double* Gw; double* lam; int* counters; int* err; const int* flag; int m; int iters; double tol; double noise; };
+struct VgNewtonCheckJob { const double* Gw; double* lam; int* counters; int* err; const int* flag; int m; int iters; double tol; double noise;
+                          double null_cut = 0.0;   // > 0: pairs of rows whose PREVIOUS eigenvalues (lam on entry) were both below null_cut * largest are not judged
+};
 hipError_t vg_newton_check_launch(const VgNewtonCheckJob* jobs, int njobs, hipStream_t st);
 hipError_t vg_copy_if_launch(const int* const* err, const double* const* src_a, double* const* dst_a, const double* const* src_b,
                              double* const* dst_b, const long* n, int njobs, hipStream_t st);

@@ -1797,6 +1797,7 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
     extern __shared__ double vr_dyn[];         // m <= 128: the packed lower triangle of Gw
     __shared__ double red[16];
     __shared__ double dg[256];
+    __shared__ unsigned char nl[256];          // rows that were numerically null in the previous step (VgRefineJob::lam_prev)
     if ((int)blockIdx.x >= a.njobs) {          // rider role (see vg_eigh_kernel)
         if (threadIdx.x >= 512) return;
         vg_gemm_body<64, 16, 512>(rider, vr_dyn, blockIdx.x - a.njobs);
@@ -1805,6 +1806,20 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
     const VgRefineJob& J = a.job[blockIdx.x];
     const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double emax = J.emax > 0.0 ? J.emax : VG_POLISH_EMAX;
+    if (J.lam_prev) {                          // (the Newton chain keeps the start order: the largest is not necessarily the first)
+        if (wave == 0) {
+            double lm = 0.0;
+            for (int i = lane; i < m; i += 64) lm = fmax(lm, fabs(J.lam_prev[i]));
+            for (int off = 32; off > 0; off >>= 1) lm = fmax(lm, __shfl_xor(lm, off));
+            if (lane == 0) red[0] = lm;
+        }
+        __syncthreads();
+        if (tid < 256) nl[tid] = (tid < m && fabs(J.lam_prev[tid]) <= J.null_cut * red[0]) ? 1 : 0;
+        __syncthreads();
+    } else {
+        if (tid < 256) nl[tid] = 0;
+        __syncthreads();
+    }
     if (m <= 128) {
         // One batch of loads for the whole matrix (16 elements per thread, coalesced); the three passes below then run on
         // registers and LDS.  Gw comes straight from the previous kernel: the three dependent passes over global memory of the
@@ -1848,7 +1863,7 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
                 if (i != j) {
                     const int lo = i > j ? i : j, hi = i > j ? j : i;
                     const double gl = vr_dyn[vg_tri(lo) + hi];
-                    if (fabs(gl) > thr && !(fabs(dg[lo]) <= nfloor && fabs(dg[hi]) <= nfloor)) {
+                    if (fabs(gl) > thr && !(fabs(dg[lo]) <= nfloor && fabs(dg[hi]) <= nfloor) && !(nl[lo] && nl[hi])) {
                         const double q = gl / (dg[lo] - dg[hi]);
                         mE = fmax(mE, fabs(q));
                         if (!(fabs(q) <= emax)) mE = 1e300;                    // NaN / inf
@@ -1901,7 +1916,7 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
     for (int i = wave; i < m; i += 16)
         for (int j = lane; j < i; j += 64) {
             const double g = J.Gw[i * m + j];
-            if (fabs(g) > thr && !(fabs(dg[i]) <= nfloor && fabs(dg[j]) <= nfloor)) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
+            if (fabs(g) > thr && !(fabs(dg[i]) <= nfloor && fabs(dg[j]) <= nfloor) && !(nl[i] && nl[j])) mE = fmax(mE, fabs(g / (dg[i] - dg[j])));
         }
     for (int off = 32; off > 0; off >>= 1) mE = fmax(mE, __shfl_xor(mE, off));
     if (lane == 0) red[wave] = mE;
@@ -1914,7 +1929,7 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
         for (int j = lane; j <= i; j += 64) {
             if (j == i) { J.E[i * m + i] = 0.0; J.R1[i * m + i] = 1.0; continue; }
             const double g = J.Gw[i * m + j];
-            const double e = (ok && fabs(g) > thr && !(fabs(dg[i]) <= nfloor && fabs(dg[j]) <= nfloor)) ? g / (dg[i] - dg[j]) : 0.0;
+            const double e = (ok && fabs(g) > thr && !(fabs(dg[i]) <= nfloor && fabs(dg[j]) <= nfloor) && !(nl[i] && nl[j])) ? g / (dg[i] - dg[j]) : 0.0;
             J.E[i * m + j] = e;  J.R1[i * m + j] = e;
             J.E[j * m + i] = -e; J.R1[j * m + i] = -e;
         }
@@ -1946,7 +1961,22 @@ __global__ __launch_bounds__(1024) void vg_newton_check_kernel(const VgNewtonChe
     const VgNewtonCheckJob& J = a.job[blockIdx.x];
     const int m = J.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ double dgc[256];
+    __shared__ unsigned char nlc[256];       // rows that were numerically null in the previous step (J.lam still holds its eigenvalues here)
     double ss = 0.0, mo = 0.0, lmax = 0.0;
+    if (J.null_cut > 0.0) {
+        if (wave == 0) {
+            double lm = 0.0;
+            for (int i = lane; i < m; i += 64) lm = fmax(lm, fabs(J.lam[i]));
+            for (int off = 32; off > 0; off >>= 1) lm = fmax(lm, __shfl_xor(lm, off));
+            if (lane == 0) red[0] = lm;
+        }
+        __syncthreads();
+        if (tid < 256) nlc[tid] = (tid < m && fabs(J.lam[tid]) <= J.null_cut * red[0]) ? 1 : 0;
+        __syncthreads();
+    } else {
+        if (tid < 256) nlc[tid] = 0;
+        __syncthreads();
+    }
     for (int i = tid; i < m; i += 1024) { const double g = J.Gw[(long)i * m + i]; dgc[i] = g; J.lam[i] = g; }
     __syncthreads();
     for (int i = lane; i < m; i += 64) lmax = fmax(lmax, dgc[i]);
@@ -1956,7 +1986,7 @@ __global__ __launch_bounds__(1024) void vg_newton_check_kernel(const VgNewtonChe
         for (int j = lane; j < m; j += 64) {
             const double g = J.Gw[(long)i * m + j];
             ss += g * g;
-            if (i != j && !(fabs(dgc[i]) <= nfloor && fabs(dgc[j]) <= nfloor)) mo = fmax(mo, fabs(g));
+            if (i != j && !(fabs(dgc[i]) <= nfloor && fabs(dgc[j]) <= nfloor) && !(nlc[i] && nlc[j])) mo = fmax(mo, fabs(g));
         }
     for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); mo = fmax(mo, __shfl_xor(mo, off)); }
     if (lane == 0) { red[wave] = ss; red[16 + wave] = mo; }
