@@ -531,11 +531,11 @@ def main():
         json_out.flush()
 
 
-def timed_loop(eng, Y, yy, kind, x1, x2, m, warm, steps, warmup):
-    """ms per step of the same Adam fit loop with another plan (inducing count / warm start) on the same data."""
+def timed_loop(eng, Y, yy, kind, x1, x2, m, warm, steps, warmup, basis="points", grid=None):
+    """ms per step of the same Adam fit loop with another plan (inducing count / family / warm start) on the same data."""
     import torch
-    g = np.linspace(0, 1, m)
-    eng.plan(kind, "points", g, x1, kind, "points", g, x2, warm_start=warm)
+    g = np.linspace(0, 1, m) if grid is None else grid
+    eng.plan(kind, basis, g, x1, kind, basis, g, x2, warm_start=warm)
     opt = FitLoop5(raw_start(), lr=0.01)          # (the headline's host loop: plain floats, no numpy per-call overhead)
 
     def one():
@@ -559,6 +559,16 @@ def families_bench(eng, Y, yy, x1, x2):
     out = {}
     for kind, m in (("matern32", 128), ("matern52", 128), ("matern32", 256), ("matern12", 256)):
         out[f"{kind}_md{m}"] = timed_loop(eng, Y, yy, kind, x1, x2, m, warm=True, steps=60, warmup=20)
+    # the reference's inter-domain families: B1 hats on a mesh padded by 8 knots beyond the data on either side
+    # (gridded_kronecker_structure.py:699-724), 127 variational Fourier features on [-0.1, 1.1]; and Matern-5/2 beyond the LDS eigensolver
+    m, pad = 128, 8
+    d = 1.0 / (m - 1 - 2 * pad)
+    out["b1_padded_md128"] = timed_loop(eng, Y, yy, "matern12", x1, x2, m, warm=True, steps=100, warmup=40, basis="b1",
+                                        grid=np.linspace(-pad * d, 1 + pad * d, m))
+    M = 63
+    out["vff_127"] = timed_loop(eng, Y, yy, "matern12", x1, x2, 2 * M + 1, warm=True, steps=100, warmup=40, basis="vff",
+                                grid=np.concatenate([[-0.1, 1.1], np.arange(M + 1) * 2 * np.pi / 1.2]))
+    out["matern52_md256"] = timed_loop(eng, Y, yy, "matern52", x1, x2, 256, warm=True, steps=100, warmup=40)
     return out
 
 

@@ -25,7 +25,7 @@ ell = 0.2
 Gs = [gram(ell * (1 + dl) ** k) for k in range(3)]
 Qa = np.linalg.eigh(Gs[0])[1].T          # rows = eigenvectors
 Qb = np.linalg.eigh(Gs[1])[1].T
-def newton(S, G, tag, emax=0.3, noise=1e-13, skip=True, nullset=None):
+def newton(S, G, tag, emax=0.3, noise=1e-13, skip=True, nullset=None, cluster=None, cluster_its=1):
     for it in range(iters + 1):
         Gw = S @ G @ S.T
         dg = np.diag(Gw).copy(); off = Gw - np.diag(dg)
@@ -33,13 +33,15 @@ def newton(S, G, tag, emax=0.3, noise=1e-13, skip=True, nullset=None):
         nfl = noise * np.abs(dg).max()
         live = ~((np.abs(dg)[:, None] <= nfl) & (np.abs(dg)[None, :] <= nfl))
         if nullset is not None: live &= ~(nullset[:, None] & nullset[None, :])
+        live_rot = live.copy()
+        if cluster is not None and it < cluster_its: live_rot &= ~(cluster[:, None] & cluster[None, :])
         worst = np.abs(off * live).max()
         i, j = np.unravel_index(np.argmax(np.abs(off * live)), off.shape)
         print(f"  {tag} it {it}: max offdiag / accept = {worst / acc:9.2e}  at ({i},{j}) g_ii {dg[i]:.2e} g_jj {dg[j]:.2e}   orth err {np.abs(S @ S.T - np.eye(m)).max():.1e}")
         if it == iters: break
         thr = 1e-12 * np.linalg.norm(Gw) / m
         with np.errstate(divide="ignore", invalid="ignore"):
-            E = np.where((np.abs(off) > thr) & live, off / (dg[:, None] - dg[None, :]), 0.0)   # E_ij = g_ij / (g_ii - g_jj), skew
+            E = np.where((np.abs(off) > thr) & live_rot, off / (dg[:, None] - dg[None, :]), 0.0)   # E_ij = g_ij / (g_ii - g_jj), skew
         E[~np.isfinite(E)] = 0.0
         nbig = (np.abs(E) > emax).sum() // 2
         if skip: E[np.abs(E) > emax] = 0.0
@@ -57,3 +59,9 @@ nullset = lamb <= 1e-12 * lamb.max()
 print("static null set of", nullset.sum(), "rows:")
 newton(Qb.copy(), Gs[2], "prev+nullset", nullset=nullset)
 newton(U @ Qb, Gs[2], "extr+nullset", nullset=nullset)
+
+cluster = lamb <= 1e-7 * lamb.max()
+print("cluster of", cluster.sum(), "rows (<= 1e-7 of the largest) deferred for the first iteration(s):")
+for ci in (1, 2):
+    newton(Qb.copy(), Gs[2], f"prev+cluster{ci}", nullset=nullset, cluster=cluster, cluster_its=ci)
+    newton(U @ Qb, Gs[2], f"extr+cluster{ci}", nullset=nullset, cluster=cluster, cluster_its=ci)

@@ -12,7 +12,7 @@ X, y, x1, x2 = D.gen_grid(n, n)
 Y = torch.tensor(y.reshape(n, n), device="cuda")
 yy = float((y * y).sum())
 
-def loop(plan, steps=120, warmup=30):
+def loop(plan, steps=int(os.environ.get("TF_STEPS", 120)), warmup=30):
     plan()
     opt = bench.Adam(bench.raw_start(), lr=0.01)
     stats = {"rounds": 0, "cold": 0}

@@ -32,6 +32,7 @@ extern "C" int vggp_version(void) { return VGGP_VERSION; }
 #define VG_NEWTON_TOL 1e-12      // off-diagonal threshold of the Newton chain's rotations, relative to ||Gw||_F / m
 #define VG_NEWTON_NULL 1e-12     // rows whose eigenvalue was below this fraction of the largest in the PREVIOUS step form the known null space:
                                  // pairs inside it are neither rotated nor judged (VgRefineJob::lam_prev)
+#define VG_NEWTON_CLUSTER 1e-7   // ... and the rows below this fraction form the near-null cluster, whose internal pairs wait for the second iteration
 #define VG_NEWTON_NOISE 1e-13    // diagonal entries below this fraction of the largest are "at the rounding floor" (VgRefineJob::noise)
 #define VG_NEWTON_ACCEPT 1e-11   // ... of its convergence check: Gw = S G S^T comes out of two GEMMs with ~ eps sqrt(m) ||G|| of rounding noise per
                                  // element, 2e-15 ||G|| at m = 256 against 4e-15 ||G||_F for 1e-12 -- the chain converged TO the threshold and
@@ -334,7 +335,7 @@ extern "C" int vggp_plan(vggp_ctx* c, const vggp_desc* desc) {
     c->pred_consumed = false;
     c->acc_valid = false; c->last_warm = false; c->last_slabs = false; c->last_payload = nullptr;
     c->last_thin = false; c->thin_off = false; c->thin_block = 0;
-    c->cur_newton = 0; c->last_newton = false; c->newton_next = false; c->newton_block = 0; c->newton_iters = 3;
+    c->cur_newton = 0; c->last_newton = false; c->newton_next = false; c->newton_block = 0; c->newton_iters = 3; c->newton_ok_run = 0;
     c->desc = *desc;
     c->d[0] = VgDim();
     c->d[1] = VgDim();
@@ -1044,7 +1045,9 @@ static int finish_enqueue(vggp_ctx* c, const double* payload, double yy_total, b
                 VgDim& d = c->d[k];
                 rj[k] = VgRefineJob{d.Gw, d.U, d.TH, d.m, VG_NEWTON_TOL};
                 rj[k].emax = 0.3; rj[k].flag = d.counters2; rj[k].noise = VG_NEWTON_NOISE;
-                if (newton_null) { rj[k].lam_prev = d.lam0; rj[k].null_cut = VG_NEWTON_NULL; }
+                // first iteration: the whole near-null cluster is left alone (its block is dominated by delta^2 lam_range until the
+                // range-cluster rotations have been applied); afterwards only the exactly-null rows
+                if (newton_null) { rj[k].lam_prev = d.lam0; rj[k].null_cut = it == 0 ? VG_NEWTON_CLUSTER : VG_NEWTON_NULL; }
             }
             const VgGemmBatch* rd = !ride ? nullptr : (ride_stage == 0 ? &c->ride_proj : (ride_stage == 1 ? &c->ride_cc : nullptr));
             VG_HIP(vg_refine_launch(rj, 2, st, rd));                           // E -> U, I + E -> TH  (+ riders: S, then [C;C1;C2])
@@ -1554,8 +1557,12 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
             fprintf(stderr, "[vggp] step %ld: Newton chain (%d iterations) missed: dim1 flags %d, 10 log10(offdiag / thr) = %d; dim2 flags %d, %d\n",
                     c->seq, c->cur_newton, c->h_out->counters[0][3] & 0xff, (c->h_out->counters[0][3] >> 8) - 100,
                     c->h_out->counters[1][3] & 0xff, (c->h_out->counters[1][3] >> 8) - 100);
-        c->newton_block = 16; c->newton_next = false;
-        if (c->newton_iters < 4) ++c->newton_iters;
+        // (beyond the LDS eigensolver the regular chain is the global-memory Jacobi -- 18 ms per step at m = 256: there the chain is
+        //  tried again as soon as BOTH stored bases come from the regular chain -- the eigensolver sorts, the Newton chain keeps its
+        //  start order, and a pair of bases from different chains extrapolates badly; otherwise it rests for 16 steps)
+        c->newton_block = (c->d[0].m > 128 || c->d[1].m > 128) ? 2 : 16; c->newton_next = false;
+        if (c->newton_iters < 5) ++c->newton_iters;
+        c->newton_ok_run = 0;
         c->have_step = false;
         return VG_ESUBMISS;
     }
@@ -1582,6 +1589,10 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
     //  bases of a chain switch may not correspond row by row -- the extrapolated start is then poor, the chain that receives it
     //  notices: the regular one sweeps, the Newton chain misses and the step is repeated)
     c->last_newton = c->cur_newton > 0;
+    if (c->cur_newton > 0 && ++c->newton_ok_run >= 64) {          // a long run without a miss: try one iteration less again
+        c->newton_ok_run = 0;
+        if (c->newton_iters > 3) --c->newton_iters;
+    }
     // next step: stay on the Newton chain while it works; move to it when a warm step of the regular chain still needed rounds
     {
         const bool polished = ((c->h_out->counters[0][3] >> 28) & 1) && ((c->h_out->counters[1][3] >> 28) & 1);

@@ -104,6 +104,7 @@ struct vggp_ctx {
     bool last_newton = false, newton_next = false;
     int newton_block = 0;             // steps for which the Newton chain stays off after a miss
     int newton_iters = 3, newton_cap = 0;
+    int newton_ok_run = 0;           // Newton-chain steps since the last miss (the iteration count decays after 64)
     bool last_thin = false;           // the last finished step ran the thin chain: QtPrev holds r rows, the m-space state (beta, 1/D, E, F) is not there
     int thin_block = 0;               // steps for which the thin chain stays off after it missed
     bool thin_off = false;            // a caller needed the full m-space state of a warm step (vggp_zgrad): keep to the full chain from now on
