@@ -1390,7 +1390,9 @@ static int vg_start_prepare(vggp_ctx* c, bool warm, hipStream_t st, VgStart* out
         static const bool off = getenv("VGGP_NO_NEWTON_CHAIN") != nullptr;
         static const char* ite = getenv("VGGP_NEWTON_ITERS");
         const bool big = c->d[0].m > 128 || c->d[1].m > 128;
-        const bool want = warm && !out->subspace && out->extrap && !off && c->newton_block == 0 && (big || c->newton_next) &&
+        // (below m_d = 96 a sweep of the LDS solver is cheaper than an iteration of this chain -- seven launches whatever the size)
+        const bool roomy = c->d[0].m >= 96 && c->d[1].m >= 96;
+        const bool want = warm && !out->subspace && out->extrap && !off && c->newton_block == 0 && (big || (c->newton_next && roomy)) &&
                           !(c->desc.flags & VGGP_FLAG_BLOCK_JACOBI) && c->d[0].m >= 8 && c->d[1].m >= 8;
         out->newton = want ? (ite ? atoi(ite) : c->newton_iters) : 0;
         if (c->newton_block > 0) --c->newton_block;
@@ -1600,7 +1602,9 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
                          (c->last_warm && c->cur_extrap && !c->cur_thin && !polished && (c->h_out->counters[0][0] + c->h_out->counters[1][0]) > 0) ||
                          // ... or ended in the polish only after more than a sweep and a half of rotations (B1 hats on a padded mesh: two
                          // dense sweeps per step, then the polish; an occasional single sweep of a Matern-3/2 step does not count)
-                         (c->last_warm && c->cur_extrap && !c->cur_thin &&
+                         // (m_d >= 96 only: an iteration of the chain is seven launches whatever the size, a sweep of a small matrix is cheap --
+                         //  127 Fourier features gain, 63 lose)
+                         (c->last_warm && c->cur_extrap && !c->cur_thin && c->d[0].m >= 96 && c->d[1].m >= 96 &&
                           (2 * c->h_out->counters[0][0] >= 3 * c->d[0].m || 2 * c->h_out->counters[1][0] >= 3 * c->d[1].m));
     }
     if (++c->warm_run >= 512) {                                // periodic cold restart: bounds the drift of orthogonality
