@@ -1525,13 +1525,13 @@ static int finish_collect(vggp_ctx* c, double* elbo_out, double grad_out[5], vgg
             int want = 0;
             static const bool relax = getenv("VGGP_NO_SUB_RELAX") == nullptr;
             if (d.Zs && rank >= 1 && 3 * rank <= d.m) {
-                // numerical rank (eigenvalues above 1e-14 of the largest) + 3 rows, rounded up to a multiple of 4: at 1024^2, m_d = 128
-                // that is 20 rows (rank 17); the earlier rule (rank + 4 rounded to 8 = 24 rows) cost 11 us per step in the row QR, the
+                // numerical rank (eigenvalues above 1e-14 of the largest) + 3 rows, rounded up to an even count (odd counts run a padded,
+                // slower path: 21 rows 0.207 ms, 22 rows 0.190): at 1024^2, m_d = 128 that is 20 rows (rank 17), 22 when the rank reaches 18; the earlier rule (rank + 4 rounded to 8 = 24 rows) cost 11 us per step in the row QR, the
                 // Ritz solve and the r-row products.  An RBF spectrum drops by ~6x per index and a fit-loop step moves it by a few
                 // per cent, so the margin is consumed one row per many steps -- and the tail kernel's miss check catches the rest.
                 // VGGP_SUB_MARGIN8=1: the earlier rule.
                 static const bool m8 = getenv("VGGP_SUB_MARGIN8") != nullptr;
-                want = m8 ? ((rank + 4 + 7) / 8) * 8 : ((rank + 3 + 3) / 4) * 4;
+                want = m8 ? ((rank + 4 + 7) / 8) * 8 : ((rank + 3 + 1) / 2) * 2;
                 if (want < 16) want = 16;
                 if (want > 64 || 2 * want > d.m) want = 0;
             } else if (relax && d.Zs && rank >= 1 && d.m <= 64 && rank + 2 <= d.m - 8) {
