@@ -1891,6 +1891,58 @@ __global__ __launch_bounds__(1024) void vg_refine_kernel(const VgRefineArgs a, c
         }
         return;
     }
+    if (J.flag) {
+        // Newton chain, m > 128: ONE pass over the lower triangle instead of three dependent ones (norm, largest quotient, output) --
+        // 93 us per launch at m = 256, three launches per step.  The element threshold comes from the diagonal alone (its norm is a
+        // lower bound of the Frobenius norm: a few more negligible elements get a quotient), and a quotient above emax raises the
+        // reject bit but no longer blanks E: the chain's last kernel refuses the result anyway and the stored bases stay untouched.
+        for (int i = tid; i < m; i += 1024) dg[i] = J.Gw[i * m + i];
+        __syncthreads();
+        double sd = 0.0, dm = 0.0;
+        for (int i = lane; i < m; i += 64) { sd += dg[i] * dg[i]; dm = fmax(dm, fabs(dg[i])); }
+        for (int off = 32; off > 0; off >>= 1) { sd += __shfl_xor(sd, off); dm = fmax(dm, __shfl_xor(dm, off)); }
+        const double thr1 = (J.tol > 0.0 ? J.tol : VG_EIG_TOL) * sqrt(sd) / (double)m;
+        const double nfl1 = J.noise > 0.0 ? J.noise * dm : -1.0;
+        bool big = false;
+        // 64 x 64 tiles of the lower block triangle through LDS, so that BOTH the tile and its mirror image are written with
+        // coalesced rows (the mirror image straight from the registers was 64 cache lines per store instruction)
+        double* tl = vr_dyn;                                   // [64][65]
+        const int nbt = (m + 63) >> 6, tr = tid >> 6, tc = tid & 63;
+        for (int bi = 0; bi < nbt; ++bi)
+            for (int bj = 0; bj <= bi; ++bj) {
+                double ev[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = tr + 16 * u, ii = bi * 64 + r, jj = bj * 64 + tc;
+                    double e = 0.0;
+                    if (ii < m && jj < m && jj < ii) {
+                        const double g = J.Gw[ii * m + jj];
+                        if (fabs(g) > thr1 && !(fabs(dg[ii]) <= nfl1 && fabs(dg[jj]) <= nfl1) && !(nl[ii] && nl[jj])) {
+                            e = g / (dg[ii] - dg[jj]);
+                            if (!(fabs(e) <= emax)) { big = true; e = 0.0; }
+                        }
+                    }
+                    ev[u] = e;
+                    tl[r * 65 + tc] = e;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = tr + 16 * u, ii = bi * 64 + r, jj = bj * 64 + tc;
+                    if (bi != bj) {
+                        if (ii < m && jj < m) { J.E[ii * m + jj] = ev[u]; J.R1[ii * m + jj] = ev[u]; }
+                        const int i2 = bj * 64 + r, j2 = bi * 64 + tc;            // mirror tile, element (i2, j2) = -e(j2, i2)
+                        if (i2 < m && j2 < m) { const double t = -tl[tc * 65 + r]; J.E[i2 * m + j2] = t; J.R1[i2 * m + j2] = t; }
+                    } else if (ii < m && jj < m) {                                // diagonal tile: lower part as computed, upper part mirrored
+                        const double t = jj < ii ? ev[u] : (jj > ii ? -tl[tc * 65 + r] : 0.0);
+                        J.E[ii * m + jj] = t; J.R1[ii * m + jj] = jj == ii ? 1.0 : t;
+                    }
+                }
+                __syncthreads();
+            }
+        if (__any(big) && lane == 0) atomicOr(J.flag, 2);
+        return;
+    }
     // a wave takes whole rows (coalesced, no integer division); m <= 256: at most 4 column chunks and 16 rows per wave
     double ss = 0.0;
     for (int i = wave; i < m; i += 16)
@@ -1949,6 +2001,7 @@ hipError_t vg_refine_launch(const VgRefineJob* jobs, int njobs, hipStream_t st, 
     size_t lds = 0;
     for (int j = 0; j < njobs; ++j)
         if (jobs[j].m <= 128) lds = std::max(lds, (size_t)jobs[j].m * (jobs[j].m + 1) / 2 * sizeof(double));
+        else if (jobs[j].flag) lds = std::max(lds, (size_t)64 * 65 * sizeof(double));      // the tile buffer of the one-pass path
     if (rb.total_tiles > 0) lds = std::max(lds, (size_t)(2 * VgTile<64, 16>::TILE * sizeof(double)));
     hipLaunchKernelGGL(vg_refine_kernel, dim3(njobs + rb.total_tiles), dim3(1024), lds, st, a, rb);
     return hipGetLastError();
