@@ -316,7 +316,11 @@ size_t vg_thin_tail_lds(int r1, int r2) {
     return (size_t)VT_NBUF * mp * (mp + 2) * sizeof(double);
 }
 
-hipError_t vg_thin_tail_setup() {
+__global__ void vg_pivchol_kernel(const VgPivCholArgs a);
+hipError_t vg_thin_tail_setup() {          // per device, at vggp_create: the dynamic-LDS ceilings of this file's kernels
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vg_pivchol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(256 * 65 * sizeof(double)));      // m <= 256 rows x (r <= 64) + 1 columns
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(vg_thin_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)vg_thin_tail_lds(VT_MAXR, VT_MAXR));
 }
@@ -397,11 +401,6 @@ hipError_t vg_pivchol_launch(const VgPivCholJob* jobs, int njobs, hipStream_t st
         if (jobs[i].m < 1 || jobs[i].m > VP_MAXM || jobs[i].r < 1 || jobs[i].r > jobs[i].m || jobs[i].r > 64) return hipErrorInvalidValue;
         a.job[i] = jobs[i];
         lds = std::max(lds, (size_t)jobs[i].m * (jobs[i].r + 1) * sizeof(double));
-    }
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vg_pivchol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(VP_MAXM * 65 * sizeof(double)));
-        attr = true;
     }
     hipLaunchKernelGGL(vg_pivchol_kernel, dim3(njobs), dim3(256), lds, st, a);
     return hipGetLastError();
