@@ -507,8 +507,9 @@ def main():
             }
         if world == 1 and not args.no_extras and not args.masked:
             out["cold_ms_per_step"] = timed_loop(eng, Y, yy, args.kind, x1, x2, m, warm=False, steps=40, warmup=5)
-            out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=40 if md < 256 else 12,
-                                                    warmup=10 if md < 256 else 4) for md in (32, 64, 128, 256)}
+            # (40 warm-up steps: the warm chains settle -- ranks, row counts, their captured graphs -- over the first few dozen steps)
+            out["m_d_sweep"] = {str(md): timed_loop(eng, Y, yy, args.kind, x1, x2, md, warm=True, steps=100, warmup=40)
+                                for md in (32, 64, 128, 256)}
             out["families"] = families_bench(eng, Y, yy, x1, x2)
             out["fit_predict_loop"] = fit_predict_bench(eng, Y, yy, args.kind, x1, x2, m)
             out["slab_1024x4096"] = slab_bench(eng, D, args.kind, m)
