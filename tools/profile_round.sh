@@ -33,7 +33,8 @@ run factor_write --pmc WRITE_SIZE -- $R/tools/time_factor.py        &&
 run trsm_kron -- $R/tools/time_trsm.py                              &&
 run masked -- $R/bench.py --masked --n 2048 --m 32 --steps 20 --warmup 5 --no-cpu &&
 run md256 -- $R/tools/time_md256.py rbf matern32                    &&
-run masked_iter -- $R/tools/time_masked_iter.py
+run masked_iter -- $R/tools/time_masked_iter.py                     &&
+run families -- $R/tools/time_families.py b1 vff "matern52 points m=128"
 cd $R
 python3 tools/trace_step.py $O/step_kernel_trace.csv > $O/step_timeline.txt 2>&1
 python3 tools/trace_step.py $O/step_m32_kernel_trace.csv > $O/step_m32_timeline.txt 2>&1
